@@ -1,0 +1,655 @@
+"""CPU restatement (numpy, fp32) of the reference's YOLO inference hot path.
+
+**TEST INFRASTRUCTURE ONLY** -- this module is the parity oracle.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the product
+(`yolo_tensorflow_amd/`) never does and fails loudly when its HIP library is missing.
+
+Parity status: the reference's TF graph cannot run here (TensorFlow absent, its
+kernels un-vendored, TF 1.5-1.8 per V1/README.md:3, V3/README.md:5), so the TF-only ops are
+restated from their published closed forms; every function that *can* be pinned is pinned by
+tests/test_oracle_*.py:
+  * conv / BN / leaky / maxpool / shortcut / route / yolo+region decode / darknet NMS, and the whole
+    network in `semantics="darknet"`: against the reference's own C code compiled into oracle/_ref
+    (oracle/Makefile), fixtures in tests/golden/ (tools/make_golden.py);
+  * numpy NMS `non_max_suppression`/`_iou` (V3/yolo_v3.py:350-420) and V2 `postprocess`/`bboxes_*`
+    (V2/utils.py:30-187): bit-for-bit against the reference functions imported in the build
+    container, golden vectors committed;
+  * `resize_bilinear` (legacy), `_upsample`, `space_to_depth`, `tf.image.non_max_suppression`:
+    **parity unpinned** by any reference artefact -- restated from the TF-1.x kernel semantics and
+    checked against hand-derived closed forms only.
+
+Layout convention: activations NHWC float32 (the reference's `data_format='NHWC'` path), conv
+weights HWIO, exactly as the TF graph holds them after `load_weights`.
+"""
+import numpy as np
+
+LEAKY = 0.1          # V3/yolo_v3.py:10
+BN_EPS_TF = 1e-5     # V3/yolo_v3.py:9
+
+
+# ----------------------------------------------------------------------------------------------
+# numeric helpers
+# ----------------------------------------------------------------------------------------------
+def to_bf16(x):
+    """Round float32 -> bfloat16 (round-to-nearest-even) and return as float32 (for emulating the
+    device's storage precision; not part of the reference)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    out = ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+    return np.where(np.isnan(x), x, out)
+
+
+def sigmoid(x):
+    x = np.asarray(x, dtype=np.float32)
+    return (np.float32(1) / (np.float32(1) + np.exp(-x, dtype=np.float32))).astype(np.float32)
+
+
+def leaky_relu(x, alpha=LEAKY):
+    # tf.nn.leaky_relu = max(alpha*x, x)  (V3/yolo_v3.py:229; V2/model_darknet19_slim.py:111-116)
+    return np.maximum(np.float32(alpha) * x, x)
+
+
+# ----------------------------------------------------------------------------------------------
+# row L: darknet .weights <-> tensors          (V3/yolo_v3.py:270-326, DN/parser.c:1163-1239)
+# ----------------------------------------------------------------------------------------------
+def parse_cfg(text):
+    """Darknet INI-style topology -> list of {'type':..., key: str}.  DN/parser.c:730-875."""
+    secs = []
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line[0] in "#;":
+            continue
+        if line.startswith("["):
+            secs.append({"type": line.strip("[]").strip()})
+        else:
+            k, v = line.split("=", 1)
+            secs[-1][k.strip()] = v.strip()
+    return secs
+
+
+def conv_layers(secs):
+    """(index_in_layers, filters, size, stride, bn, act, cin) for every conv in cfg order."""
+    out = []
+    for i, s, shp in _walk_shapes(secs):
+        if s["type"] == "convolutional":
+            out.append(dict(idx=i, filters=int(s["filters"]), size=int(s["size"]),
+                            stride=int(s.get("stride", 1)), bn=int(s.get("batch_normalize", 0)),
+                            act=s.get("activation", "logistic"), cin=shp["cin"]))
+    return out
+
+
+def _walk_shapes(secs):
+    net = secs[0]
+    H, W, C = int(net["height"]), int(net["width"]), int(net["channels"])
+    shapes = []
+    for i, s in enumerate(secs[1:]):
+        t = s["type"]
+        cin = C
+        if t == "convolutional":
+            k, st = int(s["size"]), int(s.get("stride", 1))
+            pad = k // 2 if int(s.get("pad", 0)) else int(s.get("padding", 0))
+            H, W, C = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1, int(s["filters"])
+        elif t == "maxpool":
+            st = int(s.get("stride", 1)); k = int(s.get("size", st))
+            pad = int(s.get("padding", (k - 1) // 2))
+            H, W = (H + 2 * pad) // st, (W + 2 * pad) // st
+        elif t == "upsample":
+            st = int(s.get("stride", 2)); H, W = H * st, W * st
+        elif t == "reorg":
+            st = int(s.get("stride", 1)); H, W, C = H // st, W // st, C * st * st
+        elif t == "route":
+            ls = [int(x) for x in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            H, W = shapes[ls[0]][0], shapes[ls[0]][1]
+            C = sum(shapes[l][2] for l in ls)
+        elif t == "shortcut":
+            pass
+        elif t in ("yolo", "region", "detection"):
+            pass
+        else:
+            raise ValueError("unsupported layer type " + t)
+        shapes.append((H, W, C))
+        yield i, s, dict(cin=cin, H=H, W=W, C=C)
+
+
+def read_darknet_weights(path, secs, header_ints=None):
+    """Return per-conv list of dicts {bias|beta,gamma,mean,var, w_hwio}.
+
+    header: 5 x int32 for v3 / v3-tiny (V3/yolo_v3.py:278), 4 x int32 for v2 / tiny-voc / v1-tiny
+    (D2T/YOLO_V2_convert...py:351); when `header_ints` is None apply darknet's own rule
+    (DN/parser.c:1259-1265): major*10+minor >= 2 -> 64-bit `seen`."""
+    raw = np.fromfile(path, dtype=np.int32, count=3)
+    if header_ints is None:
+        header_ints = 5 if (raw[0] * 10 + raw[1]) >= 2 else 4
+    with open(path, "rb") as f:
+        np.fromfile(f, dtype=np.int32, count=header_ints)
+        flat = np.fromfile(f, dtype=np.float32)
+    return unflatten_weights(flat, secs)
+
+
+def unflatten_weights(flat, secs):
+    ptr = 0
+    out = []
+    for c in conv_layers(secs):
+        n, k, cin = c["filters"], c["size"], c["cin"]
+        p = {}
+        if c["bn"]:
+            # file order: biases(beta), scales(gamma), rolling_mean, rolling_variance
+            for name in ("beta", "gamma", "mean", "var"):
+                p[name] = flat[ptr:ptr + n].copy(); ptr += n
+        else:
+            p["bias"] = flat[ptr:ptr + n].copy(); ptr += n
+        cnt = n * cin * k * k
+        w = flat[ptr:ptr + cnt].reshape(n, cin, k, k); ptr += cnt       # OIHW
+        p["w_hwio"] = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))  # V3/yolo_v3.py:319-321
+        out.append(p)
+    if ptr != flat.size:
+        raise ValueError(f"weights stream has {flat.size} floats, topology consumes {ptr}")
+    return out
+
+
+def fold_bn(p, eps=BN_EPS_TF):
+    """W' = W*gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps)  (SURVEY 8a row C).
+    fp32 arithmetic -- this is the load-time transformation the product applies."""
+    if "bias" in p:
+        return p["w_hwio"].astype(np.float32), p["bias"].astype(np.float32)
+    s = (p["gamma"] / np.sqrt(p["var"] + np.float32(eps))).astype(np.float32)
+    return (p["w_hwio"] * s[None, None, None, :]).astype(np.float32), \
+           (p["beta"] - p["mean"] * s).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# row P: input processing
+# ----------------------------------------------------------------------------------------------
+def resize_bilinear_legacy(img, out_h, out_w):
+    """TF-1.x `tf.image.resize_images` / `resize_bilinear(align_corners=False)`: src = dst*(in/out),
+    no half-pixel offset, upper index clamped; value = top + (bottom-top)*y_lerp with
+    top = tl + (tr-tl)*x_lerp (resize_bilinear_op.cc compute_lerp).  img [H,W,C] or [N,H,W,C] f32."""
+    img = np.asarray(img, dtype=np.float32)
+    squeeze = img.ndim == 3
+    if squeeze:
+        img = img[None]
+    N, H, W, C = img.shape
+    hs = np.float32(H) / np.float32(out_h)
+    ws = np.float32(W) / np.float32(out_w)
+    ys = (np.arange(out_h, dtype=np.float32) * hs).astype(np.float32)
+    xs = (np.arange(out_w, dtype=np.float32) * ws).astype(np.float32)
+    y0 = np.floor(ys).astype(np.int64); y1 = np.minimum(y0 + 1, H - 1); yl = (ys - y0).astype(np.float32)
+    x0 = np.floor(xs).astype(np.int64); x1 = np.minimum(x0 + 1, W - 1); xl = (xs - x0).astype(np.float32)
+    tl = img[:, y0][:, :, x0]; tr = img[:, y0][:, :, x1]
+    bl = img[:, y1][:, :, x0]; br = img[:, y1][:, :, x1]
+    xl = xl[None, None, :, None]; yl = yl[None, :, None, None]
+    top = tl + (tr - tl) * xl
+    bot = bl + (br - bl) * xl
+    out = (top + (bot - top) * yl).astype(np.float32)
+    return out[0] if squeeze else out
+
+
+def input_process(image_u8, size):
+    """D2T/YOLO_V3_convert...py:106-111: uint8 HWC -> float /255.0 -> bilinear stretch -> [1,S,S,3]."""
+    x = image_u8.astype(np.float32) / np.float32(255.0)
+    return resize_bilinear_legacy(x, size, size)[None]
+
+
+# ----------------------------------------------------------------------------------------------
+# rows C, Cb, M, U, R, Rt, B: operators
+# ----------------------------------------------------------------------------------------------
+def conv2d_nhwc(x, w_hwio, stride=1, pad=None):
+    """Cross-correlation, zero padding `pad` each side (k//2 by default == TF SAME at stride 1 and
+    `_fixed_padding`+VALID at stride 2, V3/yolo_v3.py:47-51,63-90; == darknet pad=1,
+    DN/parser.c:186-187).  im2col + sgemm, fp32."""
+    x = np.asarray(x, dtype=np.float32)
+    k = w_hwio.shape[0]
+    if pad is None:
+        pad = k // 2
+    N, H, W, C = x.shape
+    O = w_hwio.shape[3]
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    wm = w_hwio.reshape(k * k * C, O).astype(np.float32)
+    out = np.empty((N, Ho, Wo, O), dtype=np.float32)
+    for n in range(N):
+        xp = np.pad(x[n], ((pad, pad), (pad, pad), (0, 0))) if pad else x[n]
+        if k == 1 and stride == 1:
+            cols = xp.reshape(-1, C)
+        else:
+            win = np.lib.stride_tricks.sliding_window_view(xp, (k, k), axis=(0, 1))  # [H',W',C,k,k]
+            win = win[::stride, ::stride][:Ho, :Wo]
+            cols = np.ascontiguousarray(win.transpose(0, 1, 3, 4, 2)).reshape(Ho * Wo, k * k * C)
+        out[n] = (cols @ wm).reshape(Ho, Wo, O)
+    return out
+
+
+def batch_norm(x, p, mode="tf"):
+    """mode 'tf': slim.batch_norm inference, gamma*(x-mean)/sqrt(var+1e-5)+beta (V3/yolo_v3.py:218-224).
+    mode 'darknet_cpu': (x-mean)/(sqrt(var)+1e-6)*gamma+beta (DN/blas.c:147-158, batchnorm_layer.c:135-155)."""
+    if mode == "tf":
+        return ((x - p["mean"]) / np.sqrt(p["var"] + np.float32(BN_EPS_TF)) * p["gamma"] + p["beta"]).astype(np.float32)
+    return ((x - p["mean"]) / (np.sqrt(p["var"]) + np.float32(.000001)) * p["gamma"] + p["beta"]).astype(np.float32)
+
+
+def max_pool(x, size, stride, pad=0):
+    """slim.max_pool2d(2,'VALID') and (2, stride=1, 'SAME') (V2/model_darknet19_slim.py:141; D2T V3_Tiny
+    :445) == DN/maxpool_layer.c:79-111 with this fork's geometry out=(in+2*pad)/stride, window
+    origin -pad, out-of-range = -inf."""
+    N, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad) // stride, (W + 2 * pad) // stride
+    need_h = (Ho - 1) * stride + size - pad
+    need_w = (Wo - 1) * stride + size - pad
+    xp = np.pad(x, ((0, 0), (pad, max(0, need_h - H)), (pad, max(0, need_w - W)), (0, 0)),
+                constant_values=-np.inf)
+    out = np.full((N, Ho, Wo, C), -np.inf, dtype=np.float32)
+    for dy in range(size):
+        for dx in range(size):
+            out = np.maximum(out, xp[:, dy:dy + Ho * stride:stride, dx:dx + Wo * stride:stride, :])
+    return out
+
+
+def upsample_tf(x):
+    """`_upsample` (V3/yolo_v3.py:162-192): SYMMETRIC pad 1 -> legacy resize_bilinear to (2H+4,2W+4)
+    -> crop [2:-2].  Evaluated literally (pad, resize, crop), not through the closed form."""
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)), mode="symmetric")
+    N, H, W, C = x.shape
+    r = resize_bilinear_legacy(xp, 2 * H + 4, 2 * W + 4)
+    return np.ascontiguousarray(r[:, 2:-2, 2:-2, :])
+
+
+def upsample_tf_closed_form(x):
+    """SURVEY 8a row U closed form: out[2i]=in[i]; out[2i+1]=in[i]+(in[min(i+1,H-1)]-in[i])*0.5,
+    separably (x first, then y) -- what the device kernel evaluates."""
+    def up1(a, axis):
+        a = np.moveaxis(a, axis, 0)
+        nxt = np.concatenate([a[1:], a[-1:]], axis=0)
+        odd = a + (nxt - a) * np.float32(0.5)
+        out = np.empty((2 * a.shape[0],) + a.shape[1:], dtype=np.float32)
+        out[0::2] = a; out[1::2] = odd
+        return np.moveaxis(out, 0, axis)
+    return up1(up1(x.astype(np.float32), 2), 1)
+
+
+def upsample_nearest(x, stride=2):
+    """darknet upsample_cpu (DN/blas.c:334-350), scale 1."""
+    return np.repeat(np.repeat(x, stride, axis=1), stride, axis=2)
+
+
+def space_to_depth(x, s=2):
+    """tf.space_to_depth NHWC (V2/model_darknet19_slim.py:44-45): out[n,h,w,(dy*s+dx)*C+c]=in[n,h*s+dy,w*s+dx,c]."""
+    N, H, W, C = x.shape
+    x = x.reshape(N, H // s, s, W // s, s, C).transpose(0, 1, 3, 2, 4, 5)
+    return np.ascontiguousarray(x.reshape(N, H // s, W // s, s * s * C))
+
+
+def reorg_darknet(x, s=2):
+    """darknet forward_reorg_layer -> reorg_cpu(forward=0) (DN/reorg_layer.c:91-111, DN/blas.c:9-30),
+    restated on NCHW flat buffers then returned NHWC."""
+    N, H, W, C = x.shape
+    xin = np.ascontiguousarray(x.transpose(0, 3, 1, 2)).reshape(N, -1)
+    out = np.empty_like(xin)
+    out_c = C // (s * s)
+    k, j, i = np.meshgrid(np.arange(C), np.arange(H), np.arange(W), indexing="ij")
+    in_index = i + W * (j + H * k)
+    c2 = k % out_c; off = k // out_c
+    w2 = i * s + off % s; h2 = j * s + off // s
+    out_index = w2 + W * s * (h2 + H * s * c2)
+    out[:, in_index.ravel()] = xin[:, out_index.ravel()]
+    return np.ascontiguousarray(out.reshape(N, C * s * s, H // s, W // s).transpose(0, 2, 3, 1))
+
+
+# ----------------------------------------------------------------------------------------------
+# rows D3, X, S, D2, D1: decode
+# ----------------------------------------------------------------------------------------------
+def detection_layer_pixel(pred, anchors, img_size):
+    """`_detection_layer` V3/yolo_v3.py:111-159 (NHWC branch).  pred [N,g,g,A*(5+C)] raw conv output.
+    Returns [N, g*g*A, 5+C] = (cx,cy,w,h in input pixels, obj, cls...).  True division at :131."""
+    N, gy, gx, ch = pred.shape
+    A = len(anchors); attrs = ch // A
+    p = pred.reshape(N, gy * gx * A, attrs).astype(np.float32)
+    stride = (img_size[0] // gy, img_size[1] // gx)
+    anc = np.array([(a[0] / stride[0], a[1] / stride[1]) for a in anchors], dtype=np.float32)
+    centers = sigmoid(p[..., 0:2]); conf = sigmoid(p[..., 4:5])
+    a, b = np.meshgrid(np.arange(gy, dtype=np.float32), np.arange(gx, dtype=np.float32))
+    xy = np.concatenate([a.reshape(-1, 1), b.reshape(-1, 1)], axis=-1)
+    xy = np.tile(xy, [1, A]).reshape(1, -1, 2)
+    centers = (centers + xy) * np.array(stride, dtype=np.float32)
+    sizes = np.exp(p[..., 2:4]) * np.tile(anc, [gy * gx, 1]) * np.array(stride, dtype=np.float32)
+    cls = sigmoid(p[..., 5:])
+    return np.concatenate([centers, sizes, conf, cls], axis=-1).astype(np.float32)
+
+
+def detection_layer_ratio(pred, anchors, img_size):
+    """`_ratio_detection_layer` V3/YOLOV3.py:168-238 == D2T `_detection_layer` :363-433: normalised
+    (cx,cy,w,h) = (sigmoid+cell)/g, exp*anchor/stride/g."""
+    N, gy, gx, ch = pred.shape
+    A = len(anchors); attrs = ch // A
+    p = pred.reshape(N, gy * gx * A, attrs).astype(np.float32)
+    a, b = np.meshgrid(np.arange(gy, dtype=np.float32), np.arange(gx, dtype=np.float32))
+    xy = np.concatenate([a.reshape(-1, 1), b.reshape(-1, 1)], axis=-1)
+    xy = np.tile(xy, [1, A]).reshape(1, -1, 2)
+    grid = np.array([gy, gx], dtype=np.float32)
+    centers = (sigmoid(p[..., 0:2]) + xy) / grid
+    stride = (img_size[0] // gy, img_size[1] // gx)
+    anc = np.array([(1.0 * a_[0] / stride[0], 1.0 * a_[1] / stride[1]) for a_ in anchors], dtype=np.float32)
+    sizes = np.exp(p[..., 2:4]) * np.tile(anc, [gy * gx, 1]) / grid
+    return np.concatenate([centers, sizes, sigmoid(p[..., 4:5]), sigmoid(p[..., 5:])], axis=-1).astype(np.float32)
+
+
+def detections_boxes(det):
+    """V3/yolo_v3.py:329-347: (cx,cy,w,h) -> (x0,y0,x1,y1), w/2 form."""
+    cx, cy, w, h = det[..., 0:1], det[..., 1:2], det[..., 2:3], det[..., 3:4]
+    w2 = w / np.float32(2); h2 = h / np.float32(2)
+    return np.concatenate([cx - w2, cy - h2, cx + w2, cy + h2, det[..., 4:]], axis=-1).astype(np.float32)
+
+
+def select_threshold(det, score_threshold):
+    """V3/YOLOV3.py:347-362 for ONE image ([rows,5+C]): corners via w*0.5, score=obj*cls, argmax/max,
+    strict `>`; order-preserving boolean_mask.  Returns boxes[x0,y0,x1,y1], scores, classes, row idx."""
+    cx, cy, w, h = det[:, 0], det[:, 1], det[:, 2], det[:, 3]
+    w2 = w * np.float32(0.5); h2 = h * np.float32(0.5)
+    boxes = np.stack([cx - w2, cy - h2, cx + w2, cy + h2], axis=-1).astype(np.float32)
+    sc = (det[:, 4:5] * det[:, 5:]).astype(np.float32)
+    label = np.argmax(sc, axis=-1).astype(np.int32)
+    smax = np.max(sc, axis=-1)
+    m = smax > np.float32(score_threshold)
+    return boxes[m], smax[m], label[m], np.nonzero(m)[0]
+
+
+def region_decode(pred, anchors, num_class):
+    """V2 `decode` V2/decode.py:13-47: [N,H,W,A*(5+C)] -> bboxes [N,HW,A,4] (x0,y0,x1,y1 normalised),
+    obj [N,HW,A], class_probs [N,HW,A,C] (softmax)."""
+    N, H, W, ch = pred.shape
+    A = len(anchors)
+    d = pred.reshape(N, H * W, A, num_class + 5).astype(np.float32)
+    xy = sigmoid(d[..., 0:2]); wh = np.exp(d[..., 2:4]); obj = sigmoid(d[..., 4])
+    z = d[..., 5:]
+    e = np.exp(z - z.max(axis=-1, keepdims=True))
+    cls = (e / e.sum(axis=-1, keepdims=True)).astype(np.float32)
+    xc, yc = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32))
+    xc = xc.reshape(1, -1, 1); yc = yc.reshape(1, -1, 1)
+    anc = np.asarray(anchors, dtype=np.float32)
+    bx = (xc + xy[..., 0]) / np.float32(W); by = (yc + xy[..., 1]) / np.float32(H)
+    bw = (anc[:, 0] * wh[..., 0]) / np.float32(W); bh = (anc[:, 1] * wh[..., 1]) / np.float32(H)
+    two = np.float32(2)
+    boxes = np.stack([bx - bw / two, by - bh / two, bx + bw / two, by + bh / two], axis=3).astype(np.float32)
+    return boxes, obj.astype(np.float32), cls
+
+
+def region_select(boxes, obj, cls, threshold):
+    """V2/postprocess.py:49-64 for one image: score = obj*cls, argmax/max, `>=` threshold."""
+    C = cls.shape[-1]
+    sc = (obj[..., None] * cls).reshape(-1, C)
+    b = boxes.reshape(-1, 4)
+    label = np.argmax(sc, axis=1).astype(np.int32); smax = np.max(sc, axis=1)
+    m = smax >= np.float32(threshold)
+    return b[m], smax[m], label[m], np.nonzero(m)[0]
+
+
+def v1_decode(predicts, S=7, B=2, C=20, threshold=0.2):
+    """V1 `_build_detector` V1/YOLO_V1_Inference.py:213-258 (before NMS), batch element 0 only:
+    layout [cls S*S*C | conf S*S*B | boxes S*S*B*4]; x=(bx+col)/S, w=bw^2; score=conf*cls; `>=`."""
+    p = np.asarray(predicts, dtype=np.float32)
+    idx1 = S * S * C; idx2 = idx1 + S * S * B
+    cls = p[0, :idx1].reshape(S, S, C)
+    conf = p[0, idx1:idx2].reshape(S, S, B)
+    boxes = p[0, idx2:].reshape(S, S, B, 4)
+    x_off = np.transpose(np.reshape(np.array([np.arange(S)] * S * B, dtype=np.float32), [B, S, S]), [1, 2, 0])
+    y_off = np.transpose(x_off, [1, 0, 2])
+    boxes = np.stack([(boxes[..., 0] + x_off) / np.float32(S), (boxes[..., 1] + y_off) / np.float32(S),
+                      np.square(boxes[..., 2]), np.square(boxes[..., 3])], axis=3)
+    scores = conf[..., None] * cls[:, :, None, :]
+    scores = scores.reshape(-1, C); boxes = boxes.reshape(-1, 4)
+    label = np.argmax(scores, axis=1).astype(np.int32); smax = np.max(scores, axis=1)
+    m = smax >= np.float32(threshold)
+    return boxes[m].astype(np.float32), smax[m], label[m]
+
+
+# ----------------------------------------------------------------------------------------------
+# rows N1, N2, N3 (+ darknet do_nms_sort): NMS flavours
+# ----------------------------------------------------------------------------------------------
+def _tf_iou(b, i, j):
+    """TF NonMaxSuppression IOU (non_max_suppression_op.cc): min/max-normalised corners, 0 if an
+    area <= 0.  b rows are [y0,x0,y1,x1]."""
+    f = np.float32
+    ymin_i = min(b[i, 0], b[i, 2]); xmin_i = min(b[i, 1], b[i, 3])
+    ymax_i = max(b[i, 0], b[i, 2]); xmax_i = max(b[i, 1], b[i, 3])
+    ymin_j = min(b[j, 0], b[j, 2]); xmin_j = min(b[j, 1], b[j, 3])
+    ymax_j = max(b[j, 0], b[j, 2]); xmax_j = max(b[j, 1], b[j, 3])
+    area_i = f(f(ymax_i - ymin_i) * f(xmax_i - xmin_i))
+    area_j = f(f(ymax_j - ymin_j) * f(xmax_j - xmin_j))
+    if area_i <= 0 or area_j <= 0:
+        return f(0)
+    iy0 = max(ymin_i, ymin_j); ix0 = max(xmin_i, xmin_j)
+    iy1 = min(ymax_i, ymax_j); ix1 = min(xmax_i, xmax_j)
+    inter = f(max(f(iy1 - iy0), f(0)) * max(f(ix1 - ix0), f(0)))
+    return f(inter / f(f(area_i + area_j) - inter))
+
+
+def tf_nms(boxes_yxyx, scores, max_output_size, iou_threshold):
+    """`tf.image.non_max_suppression` (TF-1.x): class-agnostic greedy; candidates by score descending
+    (ties: lower index first -- the reference kernel's heap order is unspecified, this is our stated
+    rule); a candidate is dropped when IoU with any selected box is `> iou_threshold`; stops at
+    max_output_size.  Returns selected indices (into the input) in selection order."""
+    b = np.asarray(boxes_yxyx, dtype=np.float32).reshape(-1, 4)
+    s = np.asarray(scores, dtype=np.float32)
+    order = np.argsort(-s, kind="stable")
+    sel = []
+    for i in order:
+        if len(sel) >= max_output_size:
+            break
+        ok = True
+        for j in reversed(sel):
+            if _tf_iou(b, i, j) > np.float32(iou_threshold):
+                ok = False
+                break
+        if ok:
+            sel.append(int(i))
+    return np.array(sel, dtype=np.int32)
+
+
+def np_iou_v3(box1, box2):
+    """`_iou` V3/yolo_v3.py:350-373 incl. its quirks (no clamp of negative overlap, +1e-05)."""
+    b1_x0, b1_y0, b1_x1, b1_y1 = box1
+    b2_x0, b2_y0, b2_x1, b2_y1 = box2
+    int_x0 = max(b1_x0, b2_x0); int_y0 = max(b1_y0, b2_y0)
+    int_x1 = min(b1_x1, b2_x1); int_y1 = min(b1_y1, b2_y1)
+    int_area = (int_x1 - int_x0) * (int_y1 - int_y0)
+    b1_area = (b1_x1 - b1_x0) * (b1_y1 - b1_y0)
+    b2_area = (b2_x1 - b2_x0) * (b2_y1 - b2_y0)
+    return int_area / (b1_area + b2_area - int_area + 1e-05)
+
+
+def np_nms_v3(predictions_with_boxes, confidence_threshold, iou_threshold=0.4):
+    """`non_max_suppression` V3/yolo_v3.py:376-420, restated with its behaviours kept: objectness-only
+    gate (:385), class = argmax cls (:397), per class sort by objectness desc (:404, numpy default
+    argsort reversed), greedy keep `iou < thr` (:416), result dict shared across the batch (:388),
+    scores indexed through the mask built on cls_boxes[1:] (:414-418, the off-by-one)."""
+    p = np.asarray(predictions_with_boxes)
+    conf_mask = np.expand_dims(p[:, :, 4] > confidence_threshold, -1)
+    predictions = p * conf_mask
+    result = {}
+    for image_pred in predictions:
+        shape = image_pred.shape
+        nz = np.nonzero(image_pred)
+        image_pred = image_pred[nz].reshape(-1, shape[-1])
+        bbox_attrs = image_pred[:, :5]
+        classes = np.argmax(image_pred[:, 5:], axis=-1)
+        for cls in list(set(classes.reshape(-1))):
+            cls_boxes = bbox_attrs[np.nonzero(classes == cls)]
+            cls_boxes = cls_boxes[cls_boxes[:, -1].argsort()[::-1]]
+            cls_scores = cls_boxes[:, -1]
+            cls_boxes = cls_boxes[:, :-1]
+            while len(cls_boxes) > 0:
+                box = cls_boxes[0]; score = cls_scores[0]
+                result.setdefault(cls, []).append((box, score))
+                cls_boxes = cls_boxes[1:]
+                ious = np.array([np_iou_v3(box, x) for x in cls_boxes])
+                keep = np.nonzero(ious < iou_threshold)
+                cls_boxes = cls_boxes[keep]
+                cls_scores = cls_scores[keep]
+    return result
+
+
+def v2_bboxes_iou(b1, b2):
+    """V2/utils.py:155-174 (clamped overlap; division by zero possible for degenerate int boxes)."""
+    b1 = np.transpose(b1); b2 = np.transpose(b2)
+    int_ymin = np.maximum(b1[0], b2[0]); int_xmin = np.maximum(b1[1], b2[1])
+    int_ymax = np.minimum(b1[2], b2[2]); int_xmax = np.minimum(b1[3], b2[3])
+    int_h = np.maximum(int_ymax - int_ymin, 0.); int_w = np.maximum(int_xmax - int_xmin, 0.)
+    int_vol = int_h * int_w
+    vol1 = (b1[2] - b1[0]) * (b1[3] - b1[1]); vol2 = (b2[2] - b2[0]) * (b2[3] - b2[1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return int_vol / (vol1 + vol2 - int_vol)
+
+
+def v2_postprocess(bboxes, obj_probs, class_probs, image_shape=(416, 416), threshold=0.5,
+                   top_k=400, nms_threshold=0.5):
+    """`postprocess` V2/utils.py:30-62 -> bboxes_cut :133-143, bboxes_sort :146-151, bboxes_nms :176-187."""
+    bboxes = np.reshape(np.array(bboxes, dtype=np.float32), [-1, 4])
+    bboxes[:, 0:1] *= float(image_shape[1]); bboxes[:, 1:2] *= float(image_shape[0])
+    bboxes[:, 2:3] *= float(image_shape[1]); bboxes[:, 3:4] *= float(image_shape[0])
+    bboxes = bboxes.astype(np.int32)
+    mm = [0, 0, image_shape[1] - 1, image_shape[0] - 1]
+    bboxes = np.stack([np.maximum(bboxes[:, 0], mm[0]), np.maximum(bboxes[:, 1], mm[1]),
+                       np.minimum(bboxes[:, 2], mm[2]), np.minimum(bboxes[:, 3], mm[3])], axis=1)
+    obj = np.reshape(obj_probs, [-1])
+    cls = np.reshape(class_probs, [len(obj), -1])
+    cmax = np.argmax(cls, axis=1)
+    scores = obj * cls[np.arange(len(obj)), cmax]
+    keep = scores > threshold
+    cmax, scores, bboxes = cmax[keep], scores[keep], bboxes[keep]
+    index = np.argsort(-scores)
+    cmax, scores, bboxes = cmax[index][:top_k], scores[index][:top_k], bboxes[index][:top_k]
+    kb = np.ones(scores.shape, dtype=bool)
+    for i in range(scores.size - 1):
+        if kb[i]:
+            overlap = v2_bboxes_iou(bboxes[i], bboxes[(i + 1):])
+            keep_overlap = np.logical_or(overlap < nms_threshold, cmax[(i + 1):] != cmax[i])
+            kb[(i + 1):] = np.logical_and(kb[(i + 1):], keep_overlap)
+    idx = np.where(kb)
+    return bboxes[idx], scores[idx], cmax[idx]
+
+
+def _dn_overlap(x1, w1, x2, w2):
+    f = np.float32
+    l1 = f(x1 - f(w1 / f(2))); l2 = f(x2 - f(w2 / f(2)))
+    r1 = f(x1 + f(w1 / f(2))); r2 = f(x2 + f(w2 / f(2)))
+    return f(min(r1, r2) - max(l1, l2))
+
+
+def dn_box_iou(a, b):
+    """darknet box_iou (DN/box.c:152-182) on (cx,cy,w,h) boxes, fp32 step by step."""
+    f = np.float32
+    w = _dn_overlap(a[0], a[2], b[0], b[2]); h = _dn_overlap(a[1], a[3], b[1], b[3])
+    inter = f(0) if (w < 0 or h < 0) else f(w * h)
+    union = f(f(f(a[2] * a[3]) + f(b[2] * b[3])) - inter)
+    return f(inter / union)
+
+
+def dn_nms_sort(boxes_cxcywh, probs, thresh):
+    """darknet do_nms_sort (DN/box.c:58-89): per class k, sort by prob[k] desc, zero prob[k] of any later
+    box with iou > thresh.  probs [n,classes] is modified copy-returned.  (The objectness==0 pre-filter
+    at :63-71 only reorders; survivors are identical.)"""
+    b = np.asarray(boxes_cxcywh, dtype=np.float32)
+    p = np.array(probs, dtype=np.float32)
+    n, C = p.shape
+    for k in range(C):
+        order = np.argsort(-p[:, k], kind="stable")
+        for ii in range(n):
+            i = order[ii]
+            if p[i, k] == 0:
+                continue
+            for jj in range(ii + 1, n):
+                j = order[jj]
+                if p[j, k] != 0 and dn_box_iou(b[i], b[j]) > np.float32(thresh):
+                    p[j, k] = 0
+    return p
+
+
+# ----------------------------------------------------------------------------------------------
+# whole network (rows B, Y, Net): cfg-driven forward
+# ----------------------------------------------------------------------------------------------
+def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, collect=None):
+    """Run the cfg (yolov3 == V3/yolo_v3.py:195-267; yolov2 == V2/model_darknet19_slim.py:119-200; ...)
+    on x [N,S,S,3] float32 **already scaled to 0..1** (the /255 of V3/yolo_v3.py:215 is applied by the
+    caller, as D2T `_input_process` does).
+
+    semantics 'tf'      : upsample = `_upsample` bilinear, reorg = tf.space_to_depth   (parity target)
+    semantics 'darknet' : upsample = nearest, reorg = darknet reorg_cpu                (pins vs oracle/_ref)
+    bn_mode             : see batch_norm()
+    emulate_bf16        : fold BN, round folded weights and every stored activation to bf16 -- the
+                          device's storage precision; head conv outputs stay fp32 (device keeps them fp32).
+    Returns (heads, outs): heads = list of (section, raw head tensor [N,g,g,ch] fp32) in cfg order;
+    outs = list of per-layer NHWC outputs (None for yolo/region) when collect is not None."""
+    q = to_bf16 if emulate_bf16 else (lambda a: a)
+    x = q(np.asarray(x, dtype=np.float32))
+    layers = secs[1:]
+    outs = []
+    heads = []
+    ci = 0
+    for i, s in enumerate(layers):
+        t = s["type"]
+        if t == "convolutional":
+            p = params[ci]; ci += 1
+            k, st = int(s["size"]), int(s.get("stride", 1))
+            is_head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
+            if emulate_bf16:
+                w, b = fold_bn(p)
+                y = conv2d_nhwc(x, to_bf16(w), st) + b
+            elif "bias" in p:
+                y = conv2d_nhwc(x, p["w_hwio"], st) + p["bias"]
+            else:
+                y = batch_norm(conv2d_nhwc(x, p["w_hwio"], st), p, bn_mode)
+            act = s.get("activation", "logistic")
+            if act == "leaky":
+                y = leaky_relu(y)
+            elif act != "linear":
+                raise ValueError(act)
+            x = y.astype(np.float32) if is_head else q(y.astype(np.float32))
+        elif t == "shortcut":
+            f = int(s["from"]); f = f if f >= 0 else i + f
+            x = q(outs[i - 1] + outs[f])
+        elif t == "route":
+            ls = [int(v) for v in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            x = np.concatenate([outs[l] for l in ls], axis=-1) if len(ls) > 1 else outs[ls[0]]
+        elif t == "upsample":
+            if semantics == "tf":
+                x = q(upsample_tf(x))
+            else:
+                x = upsample_nearest(x, int(s.get("stride", 2)))
+        elif t == "maxpool":
+            st = int(s.get("stride", 1)); k = int(s.get("size", st))
+            x = max_pool(x, k, st, int(s.get("padding", (k - 1) // 2)))
+        elif t == "reorg":
+            st = int(s.get("stride", 1))
+            x = space_to_depth(x, st) if semantics == "tf" else reorg_darknet(x, st)
+        elif t in ("yolo", "region"):
+            heads.append((s, outs[i - 1]))
+            outs.append(None)
+            continue
+        else:
+            raise ValueError(t)
+        outs.append(x)
+    return heads, outs
+
+
+def yolo_anchors(sec):
+    a = [float(v) for v in sec["anchors"].split(",")]
+    pairs = [(a[2 * i], a[2 * i + 1]) for i in range(len(a) // 2)]
+    if "mask" in sec:
+        pairs = [pairs[int(m)] for m in sec["mask"].split(",")]
+    return pairs
+
+
+def yolo_v3_detections(heads, img_size, ratio=False):
+    """concat of the per-scale detection layers (V3/yolo_v3.py:266): [N, sum(g*g*3), 5+C]."""
+    fn = detection_layer_ratio if ratio else detection_layer_pixel
+    return np.concatenate([fn(raw, yolo_anchors(s), (img_size, img_size)) for s, raw in heads], axis=1)
+
+
+def detect_v3_tf(det_ratio_one_image, score_threshold, iou_threshold, max_output_size):
+    """D2T YOLOV3 tail (YOLO_V3_convert...py:515-545) on one image's [rows,5+C] ratio detections:
+    -> (boxes [K,4] x0y0x1y1, scores [K], classes [K])."""
+    boxes, scores, classes, _ = select_threshold(det_ratio_one_image, score_threshold)
+    sel = tf_nms(boxes[:, [1, 0, 3, 2]], scores, max_output_size, iou_threshold)
+    return boxes[sel], scores[sel], classes[sel]

@@ -1,0 +1,156 @@
+"""Darknet topology (`.cfg`) and `.weights` stream handling for the host side.
+
+Counterpart of the reference's `load_weights` (V3/yolo_v3.py:270-326; D2T/YOLO_V3_convert...py:113-216)
+and of darknet's writer/reader (DN/parser.c:992-1067 save, :1241-1345 load): the file is
+`int32 major, minor, revision`, then `seen` (int64 when major*10+minor >= 2, else int32;
+DN/parser.c:1259-1265), then for every convolutional layer in cfg order
+`[beta|bias][gamma][mean][var]` (BN) or `[bias]`, then the filters `OIHW`.
+
+The HIP library consumes the flat float stream directly (`yolo_set_weights`); nothing here touches
+the device.  Also holds the seeded synthetic-weights generator used by bench.py and the tests
+(SURVEY.md 8d "Synthetic inputs") because no real `.weights` ships with the reference.
+"""
+import os
+import numpy as np
+
+CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg")
+
+
+def cfg_text(name):
+    """Text of a shipped topology ('yolov3', 'yolov3-608', 'yolov3-tiny', 'yolov2', 'yolov2-tiny-voc')
+    or of a cfg file path."""
+    path = name if os.path.exists(name) else os.path.join(CFG_DIR, name + ".cfg")
+    with open(path) as f:
+        return f.read()
+
+
+def with_input_size(text, size):
+    """Same topology at another square input size (kernels are shape-generic in H,W; darknet
+    `resize_network`, DN/network.c:358-438)."""
+    out = []
+    for line in text.splitlines():
+        key = line.split("=")[0].strip()
+        out.append(f"{key}={size}" if key in ("width", "height") else line)
+    return "\n".join(out)
+
+
+def parse_cfg(text):
+    secs = []
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line[0] in "#;":
+            continue
+        if line[0] == "[":
+            secs.append({"type": line[1:line.index("]")].strip()})
+        else:
+            k, v = line.split("=", 1)
+            secs[-1][k.strip()] = v.strip()
+    return secs
+
+
+def layer_shapes(secs):
+    """[(type, H, W, C_out, C_in)] per layer, darknet shape rules (DN/parser.c:730-875)."""
+    net = secs[0]
+    H, W, C = int(net["height"]), int(net["width"]), int(net["channels"])
+    shapes = []
+    for i, s in enumerate(secs[1:]):
+        t, cin = s["type"], C
+        if t == "convolutional":
+            k, st = int(s["size"]), int(s.get("stride", 1))
+            pad = k // 2 if int(s.get("pad", 0)) else int(s.get("padding", 0))
+            H, W, C = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1, int(s["filters"])
+        elif t == "maxpool":
+            st = int(s.get("stride", 1)); k = int(s.get("size", st))
+            pad = int(s.get("padding", (k - 1) // 2))
+            H, W = (H + 2 * pad) // st, (W + 2 * pad) // st
+        elif t == "upsample":
+            st = int(s.get("stride", 2)); H, W = H * st, W * st
+        elif t == "reorg":
+            st = int(s.get("stride", 1)); H, W, C = H // st, W // st, C * st * st
+        elif t == "route":
+            ls = [int(x) for x in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            H, W = shapes[ls[0]][1], shapes[ls[0]][2]
+            C = sum(shapes[l][3] for l in ls)
+        elif t not in ("shortcut", "yolo", "region"):
+            raise ValueError("unsupported layer type [%s]" % t)
+        shapes.append((t, H, W, C, cin))
+    return shapes
+
+
+def conv_specs(secs):
+    """Per conv in file order: dict(filters, size, cin, bn, head)."""
+    shapes = layer_shapes(secs)
+    layers = secs[1:]
+    out = []
+    for i, s in enumerate(layers):
+        if s["type"] == "convolutional":
+            head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
+            out.append(dict(filters=int(s["filters"]), size=int(s["size"]), cin=shapes[i][4],
+                            bn=int(s.get("batch_normalize", 0)), head=head, index=i))
+    return out
+
+
+def weights_count(secs):
+    n = 0
+    for c in conv_specs(secs):
+        n += c["filters"] * (4 if c["bn"] else 1) + c["filters"] * c["cin"] * c["size"] ** 2
+    return n
+
+
+def read_weights_file(path, header_ints=None):
+    """-> (flat float32 stream, (major, minor, revision, seen)).  `header_ints` forces the
+    reference's fixed counts (5: V3/yolo_v3.py:278; 4: D2T/YOLO_V2_convert...py:351)."""
+    with open(path, "rb") as f:
+        ver = np.fromfile(f, dtype=np.int32, count=3)
+        if ver.size < 3:
+            raise ValueError("truncated .weights header: " + path)
+        if header_ints is None:
+            header_ints = 5 if int(ver[0]) * 10 + int(ver[1]) >= 2 else 4
+        seen = np.fromfile(f, dtype=np.int64 if header_ints == 5 else np.int32, count=1)
+        flat = np.fromfile(f, dtype=np.float32)
+    return flat, (int(ver[0]), int(ver[1]), int(ver[2]), int(seen[0]) if seen.size else 0)
+
+
+def write_weights_file(path, flat, major=0, minor=2, revision=0, seen=0):
+    """Writer matching darknet `save_weights_upto` (DN/parser.c:992-1009)."""
+    with open(path, "wb") as f:
+        np.array([major, minor, revision], dtype=np.int32).tofile(f)
+        (np.array([seen], dtype=np.int64) if major * 10 + minor >= 2
+         else np.array([seen], dtype=np.int32)).tofile(f)
+        np.asarray(flat, dtype=np.float32).tofile(f)
+
+
+def synth_weights(secs, seed=0, obj_bias=-4.0):
+    """Seeded synthetic parameter stream: W ~ N(0, 2/(k*k*Cin)) (darknet's own init,
+    DN/convolutional_layer.c:205-209), gamma ~ U(.8,1.2), beta ~ N(0,.1), mean ~ N(0,.1),
+    var ~ U(.5,1.5); head convs: W ~ N(0, 1/Cin), class/box biases N(0,1)/N(0,.5), objectness
+    bias `obj_bias` so a few % of candidates pass 0.5."""
+    rng = np.random.default_rng(seed)
+    layers = secs[1:]
+    parts = []
+    for c in conv_specs(secs):
+        n, k, cin = c["filters"], c["size"], c["cin"]
+        if c["bn"]:
+            parts += [rng.normal(0, .1, n), rng.uniform(.8, 1.2, n), rng.normal(0, .1, n), rng.uniform(.5, 1.5, n)]
+            parts.append(rng.normal(0, np.sqrt(2.0 / (k * k * cin)), n * cin * k * k))
+        else:
+            b = rng.normal(0, 1.0, n)
+            if c["head"]:
+                h = layers[c["index"] + 1]
+                classes = int(h.get("classes", 20))
+                na = len(h["mask"].split(",")) if "mask" in h else int(h.get("num", 1))
+                attrs = 5 + classes
+                if na * attrs == n:
+                    b = b.reshape(na, attrs)
+                    b[:, 0:4] = rng.normal(0, .5, (na, 4))
+                    b[:, 4] = obj_bias + rng.normal(0, .5, na)
+                    b = b.reshape(-1)
+            parts.append(b)
+            parts.append(rng.normal(0, np.sqrt(1.0 / (k * k * cin)), n * cin * k * k))
+    return np.concatenate(parts).astype(np.float32)
+
+
+def default_header(secs):
+    """(major, minor) the reference's files carry: v3 family -> (0,2) 64-bit seen; region (v2) -> (0,1)."""
+    return (0, 2) if any(s["type"] == "yolo" for s in secs) else (0, 1)
