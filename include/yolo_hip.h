@@ -1,0 +1,177 @@
+/* libyolo_hip.so -- C ABI of the MI355X (gfx950) YOLO inference hot path.
+ *
+ * Drop-in boundary for the reference's "process -> runtime" call (`sess.run([...], feed_dict)`:
+ * V3/YOLO_V3_inference.py:106-107, V3/convert_ckpt_and_inference.py:88, V2/YOLO_v2.py:55,
+ * D2T/YOLO_V3_convert_darkenet_to_Tensorflow.py:588) and, on the C side, for the entry points the
+ * reference's own ctypes binding uses (D2T/darknet.py:48-115 over D2T/include/darknet.h):
+ *
+ *   reference                                              this library
+ *   ---------------------------------------------------    ---------------------------------------
+ *   load_network(cfg, weights, clear)   DN/network.c:53     yolo_create + yolo_load_darknet_weights
+ *   load_weights(var_list, file)        V3/yolo_v3.py:270   yolo_load_darknet_weights / yolo_set_weights
+ *   network_predict(net, float*)        DN/network.c:497    yolo_forward
+ *   sess.run(detections)                V3/yolo_v3.py:266   yolo_forward(..., detections_out)
+ *   get_network_boxes + do_nms_sort     DN/network.c:562,   yolo_postprocess / yolo_detect
+ *     / tf.image.non_max_suppression    DN/box.c:58, V3/YOLOV3.py:364-379
+ *   free_network                        DN/network.c:716    yolo_destroy
+ *   error(): perror+exit                DN/utils.c:253      int return code + yolo_last_error()
+ *
+ * Conventions: extern "C", plain pointers and sizes, caller-owned output buffers (no callee malloc
+ * on the hot path, unlike make_network_boxes DN/network.c:526-540), every call returns YOLO_OK or a
+ * negative code and never exits the process.  A context is single-threaded and bound to one HIP
+ * device + stream; one context per GPU.  Activations are NHWC; images are NHWC RGB.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yolo_ctx yolo_ctx;
+
+enum yolo_status {
+    YOLO_OK = 0,
+    YOLO_ERR_INVALID = -1,     /* bad argument / malformed cfg */
+    YOLO_ERR_HIP = -2,         /* HIP runtime error (text in yolo_last_error) */
+    YOLO_ERR_STATE = -3,       /* call order (e.g. forward before weights) */
+    YOLO_ERR_NOMEM = -4,
+    YOLO_ERR_IO = -5,          /* weights file missing / wrong length */
+    YOLO_ERR_UNSUPPORTED = -6
+};
+
+enum yolo_dtype { YOLO_BF16 = 0, YOLO_FP32 = 1 };          /* storage/compute type of the conv stack */
+enum yolo_semantics { YOLO_SEM_TF = 0, YOLO_SEM_DARKNET = 1 };
+/* TF: bilinear `_upsample` (V3/yolo_v3.py:162-192) + tf.space_to_depth (V2/model_darknet19_slim.py:44);
+ * DARKNET: nearest upsample (DN/blas.c:334) + reorg_cpu (DN/blas.c:9) -- lets the whole network be
+ * checked against the compiled reference. */
+enum yolo_decode { YOLO_DECODE_RATIO = 0, YOLO_DECODE_PIXEL = 1 };
+/* RATIO: `_ratio_detection_layer` V3/YOLOV3.py:168-238 (normalised); PIXEL: `_detection_layer`
+ * V3/yolo_v3.py:111-159 (input pixels).  Region (v2) heads are always normalised (V2/decode.py:13). */
+enum yolo_location { YOLO_HOST = 0, YOLO_DEVICE = 1 };
+enum yolo_image_format {
+    YOLO_IMG_U8 = 0,           /* uint8  [n,S,S,3] already at network size */
+    YOLO_IMG_F32 = 1           /* float32 [n,S,S,3] already at network size */
+};
+enum yolo_nms_mode {
+    YOLO_NMS_TF = 0,           /* tf.image.non_max_suppression: class-agnostic, `>` iou, top max_out (row N1) */
+    YOLO_NMS_PER_CLASS = 1,    /* V2 bboxes_nms (V2/utils.py:176-187): same-class, drop unless iou < thr (row N3) */
+    YOLO_NMS_DARKNET = 2       /* do_nms_sort (DN/box.c:58-89) on max-class score: same-class, drop if iou > thr */
+};
+enum yolo_select_mode {
+    YOLO_SELECT_GT = 0,        /* max(obj*cls) >  thr  (V3/YOLOV3.py:358) */
+    YOLO_SELECT_GE = 1         /* max(obj*cls) >= thr  (V2/postprocess.py:61) */
+};
+
+typedef struct yolo_config {
+    uint32_t struct_size;      /* = sizeof(yolo_config) */
+    const char *cfg_text;      /* darknet cfg text: [net] + convolutional/shortcut/route/upsample/maxpool/reorg/yolo/region */
+    int32_t max_batch;
+    int32_t dtype;             /* enum yolo_dtype */
+    int32_t semantics;         /* enum yolo_semantics */
+    int32_t decode;            /* enum yolo_decode */
+    int32_t device;            /* HIP device ordinal */
+    int32_t keep_layers;       /* 1: every layer output keeps its own buffer (yolo_layer_output valid) */
+    void *stream;              /* hipStream_t to launch on, or NULL for a context-owned stream */
+} yolo_config;
+
+/* One detection: corners in the decode's units, max class score, class id (24 bytes). */
+typedef struct yolo_box {
+    float x0, y0, x1, y1;
+    float score;
+    int32_t cls;
+} yolo_box;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* Parses the topology, plans buffers on `device`.  On failure returns NULL and writes a message to
+ * err (if non-NULL).  Replaces load_network's cfg half (DN/parser.c:730-875). */
+yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len);
+void yolo_destroy(yolo_ctx *ctx);
+const char *yolo_last_error(const yolo_ctx *ctx);
+
+/* ---- weights (row L) ------------------------------------------------------------------------ */
+/* Reads a Darknet .weights file (header rule DN/parser.c:1259-1265; header_ints 4 or 5 forces the
+ * reference loaders' fixed counts V3/yolo_v3.py:278 / D2T V2 :351, 0 = auto), folds BN
+ * (W*g/sqrt(v+1e-5), b - m*g/sqrt(v+1e-5), fp32), packs and uploads. */
+int yolo_load_darknet_weights(yolo_ctx *ctx, const char *path, int header_ints);
+/* Same from the float stream that follows the header (n floats, must match the topology). */
+int yolo_set_weights(yolo_ctx *ctx, const float *flat, size_t n);
+size_t yolo_weights_count(const yolo_ctx *ctx);
+
+/* ---- geometry ------------------------------------------------------------------------------- */
+int yolo_input_size(const yolo_ctx *ctx, int *height, int *width, int *channels);
+int yolo_num_rows(const yolo_ctx *ctx);      /* candidates per image: 10647 @416 v3, 845 v2 */
+int yolo_num_attrs(const yolo_ctx *ctx);     /* 5 + classes */
+int yolo_num_layers(const yolo_ctx *ctx);
+double yolo_conv_flops(const yolo_ctx *ctx); /* 2*k*k*Cin*Cout*Ho*Wo summed (DN/convolutional_layer.c:325), per image */
+double yolo_conv_bytes(const yolo_ctx *ctx, int n); /* algorithmic HBM bytes of the conv stack for n images */
+
+/* ---- hot path ------------------------------------------------------------------------------- */
+/* images: [n,S,S,3] in `fmt`, at `loc`; each value is multiplied by `scale` on the way in
+ * (1/255 for the `inputs / 255` of V3/yolo_v3.py:215, 1 for pre-normalised input).  Runs the conv stack
+ * and the head decode; the decoded tensor [n, rows, attrs] (V3/yolo_v3.py:266) stays resident and, when
+ * detections_out != NULL, is also copied there (fp32, at out_loc).  Asynchronous on the context stream
+ * unless a host buffer is involved. */
+int yolo_forward(yolo_ctx *ctx, const void *images, int n, int fmt, int loc, float scale,
+                 float *detections_out, int out_loc);
+
+/* Row P: ONE uint8 RGB image of any size [h,w,3] -> /255 -> legacy bilinear stretch to
+ * S x S on the device (D2T/YOLO_V3_convert...py:106-111), then as yolo_forward with n = 1. */
+int yolo_forward_image_u8(yolo_ctx *ctx, const uint8_t *image, int h, int w, int loc,
+                          float *detections_out, int out_loc);
+
+/* Threshold + NMS on the resident decoded tensor of the last forward (rows S, N1/N3).
+ * boxes_out: [n * max_out] caller-owned, counts_out: [n]; both at out_loc.
+ * Replaces get_network_boxes + do_nms_* (DN/network.c:562, DN/box.c:21-89) and the TF tail
+ * V3/YOLOV3.py:347-379. */
+int yolo_postprocess(yolo_ctx *ctx, int n, float score_thr, float iou_thr, int max_out,
+                     int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int out_loc);
+
+/* forward + postprocess. */
+int yolo_detect(yolo_ctx *ctx, const void *images, int n, int fmt, int loc, float scale,
+                float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
+                yolo_box *boxes_out, int32_t *counts_out, int out_loc);
+
+int yolo_synchronize(yolo_ctx *ctx);
+
+/* ---- introspection / measurement ------------------------------------------------------------ */
+/* Copies layer `index`'s output of the last forward as fp32 NHWC [n,H,W,C] to host (needs
+ * keep_layers=1).  dims_out receives H,W,C.  Head (yolo/region) layers return the raw conv tensor. */
+int yolo_layer_output(yolo_ctx *ctx, int index, int n, float *out, size_t out_floats, int *dims_out);
+/* Times `iters` forwards of batch n on the context stream with HIP events:
+ * total_ms = wall per forward; conv_ms = sum of the conv kernels' own durations per forward
+ * (events around every conv launch, separate pass).  Either may be NULL. */
+int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *conv_ms);
+/* Per-layer kernel time (ms, averaged over iters) for batch n into ms_out[num_layers]. */
+int yolo_time_layers(yolo_ctx *ctx, int n, int iters, float *ms_out);
+/* Tries every conv tile configuration on every conv layer at batch n and keeps the fastest. */
+int yolo_autotune(yolo_ctx *ctx, int n, int iters);
+
+/* ---- single operators on host buffers (parity tests call the production kernels through these) - */
+/* x [n,h,w,cin] fp32 NHWC, w_hwio [k,k,cin,cout], bias [cout] (or NULL), residual [n,ho,wo,cout] or NULL.
+ * act: 0 linear, 1 leaky(0.1).  pad = k/2.  out [n,ho,wo,cout] fp32.  dtype selects the kernel family;
+ * tile_cfg < 0 lets the library choose, otherwise forces one tile configuration (0..yolo_op_conv_num_cfgs()-1). */
+int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_hwio, const float *bias,
+                   int k, int stride, int cout, int act, const float *residual, float *out,
+                   int dtype, int tile_cfg, int device);
+int yolo_op_conv_num_cfgs(void);
+int yolo_op_upsample2x(const float *x, int n, int h, int w, int c, int semantics, float *out, int device);
+int yolo_op_reorg(const float *x, int n, int h, int w, int c, int stride, int semantics, float *out, int device);
+int yolo_op_maxpool(const float *x, int n, int h, int w, int c, int size, int stride, float *out, int device);
+/* legacy-bilinear stretch of one uint8 image to [s,s,3] fp32 (value/255 then resize). */
+int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float *out, int device);
+/* head decode of raw [n,g,g,na*(5+classes)] fp32: yolo (logistic) or region (softmax) */
+int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const float *anchors_wh,
+                   int img_size, int decode, int region, float *out, int device);
+/* threshold + NMS over det [n,rows,attrs] fp32 */
+int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr,
+                        int max_out, int nms_mode, int select_mode, yolo_box *boxes_out,
+                        int32_t *counts_out, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H */

@@ -1,0 +1,318 @@
+// HBM-bound NHWC operators around the conv stack: input conversion / stretch-resize (row P), 2x
+// upsample (row U), max-pool (row M), space-to-depth / darknet reorg (row R), residual add and strided
+// copies (rows B, Rt when they cannot be fused into a conv epilogue), dtype conversion for introspection.
+// One thread moves an 8-channel granule (16 B of bf16, 32 B of fp32) so global accesses are 16-B vectors
+// and consecutive lanes touch consecutive addresses along the channel axis.
+#include "kernels.h"
+#include <math.h>
+
+template <typename T> struct Elt;
+template <> struct Elt<bf16_t> {
+    static __device__ __forceinline__ void load8(const bf16_t *p, float *v)
+    {
+        uint4 u = *(const uint4 *)p;
+        uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ uint32_t cvt(float f)
+    {
+        __bf16 b = (__bf16)f;
+        return (uint32_t)__builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ __forceinline__ void store8(bf16_t *p, const float *v)
+    {
+        uint4 u;
+        u.x = cvt(v[0]) | (cvt(v[1]) << 16); u.y = cvt(v[2]) | (cvt(v[3]) << 16);
+        u.z = cvt(v[4]) | (cvt(v[5]) << 16); u.w = cvt(v[6]) | (cvt(v[7]) << 16);
+        *(uint4 *)p = u;
+    }
+    static __device__ __forceinline__ float load1(const bf16_t *p) { return __builtin_bit_cast(float, (uint32_t)(*p) << 16); }
+    static __device__ __forceinline__ void store1(bf16_t *p, float f) { *p = (bf16_t)cvt(f); }
+};
+template <> struct Elt<float> {
+    static __device__ __forceinline__ void load8(const float *p, float *v)
+    {
+        float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store8(float *p, const float *v)
+    {
+        *(float4 *)p = float4{v[0], v[1], v[2], v[3]};
+        *(float4 *)(p + 4) = float4{v[4], v[5], v[6], v[7]};
+    }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ void store1(float *p, float f) { *p = f; }
+};
+
+static inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// ---- row P: uint8/float image at network size -> 8-channel (3 real + 5 zero) activation ---------
+template <typename T>
+__global__ void k_preprocess(const void *img, int fmt, size_t npix, float scale, T *out, int out_stride)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (fmt == 0) {
+        const uint8_t *s = (const uint8_t *)img + p * 3;
+        v[0] = (float)s[0] * scale; v[1] = (float)s[1] * scale; v[2] = (float)s[2] * scale;
+    } else {
+        const float *s = (const float *)img + p * 3;
+        v[0] = s[0] * scale; v[1] = s[1] * scale; v[2] = s[2] * scale;
+    }
+    Elt<T>::store8(out + p * out_stride, v);
+}
+
+hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scale, void *out, int out_f32,
+                             int out_stride, hipStream_t s)
+{
+    size_t npix = (size_t)n * hw;
+    if (out_f32) hipLaunchKernelGGL(k_preprocess<float>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (float *)out, out_stride);
+    else hipLaunchKernelGGL(k_preprocess<bf16_t>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (bf16_t *)out, out_stride);
+    return hipGetLastError();
+}
+
+// legacy TF bilinear (no half-pixel offset): src = dst * (in/out); value/255 first (D2T _input_process)
+template <typename T>
+__global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, int out_stride, int out_c)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= so * so) return;
+    int oy = p / so, ox = p - oy * so;
+    const float hs = (float)h / (float)so, ws = (float)w / (float)so;
+    float fy = (float)oy * hs, fx = (float)ox * ws;
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    float yl = fy - (float)y0, xl = fx - (float)x0;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float tl = (float)img[((size_t)y0 * w + x0) * 3 + c] / 255.0f;
+        float tr = (float)img[((size_t)y0 * w + x1) * 3 + c] / 255.0f;
+        float bl = (float)img[((size_t)y1 * w + x0) * 3 + c] / 255.0f;
+        float br = (float)img[((size_t)y1 * w + x1) * 3 + c] / 255.0f;
+        float top = tl + (tr - tl) * xl;
+        float bot = bl + (br - bl) * xl;
+        v[c] = top + (bot - top) * yl;
+    }
+    if (out_c >= 8) Elt<T>::store8(out + (size_t)p * out_stride, v);
+    else
+        for (int c = 0; c < out_c; ++c) Elt<T>::store1(out + (size_t)p * out_stride + c, v[c]);
+}
+
+hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32, int out_stride,
+                            int out_c, hipStream_t s)
+{
+    size_t np = (size_t)s_out * s_out;
+    if (out_f32) hipLaunchKernelGGL(k_resize_u8<float>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (float *)out, out_stride, out_c);
+    else hipLaunchKernelGGL(k_resize_u8<bf16_t>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (bf16_t *)out, out_stride, out_c);
+    return hipGetLastError();
+}
+
+// ---- row U: 2x upsample.  bilinear = closed form of pad(SYMMETRIC 1) -> legacy resize_bilinear -> crop,
+//      evaluated with TF's lerp order (x then y, a + (b-a)*t, t in {0, .5}); else nearest (darknet). ----
+template <typename T>
+__global__ void k_upsample2x(const T *in, int is, T *out, int os, int n, int h, int w, int c8, int bilinear)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * 2 * h * 2 * w * c8;
+    if (idx >= total) return;
+    int g = (int)(idx % c8); size_t p = idx / c8;
+    int ox = (int)(p % (2 * w)); p /= (2 * w);
+    int oy = (int)(p % (2 * h)); int b = (int)(p / (2 * h));
+    int iy = oy >> 1, ix = ox >> 1;
+    const T *base = in + (size_t)b * h * w * is + g * 8;
+    float r[8];
+    if (!bilinear) {
+        Elt<T>::load8(base + ((size_t)iy * w + ix) * is, r);
+    } else {
+        int iy1 = min(iy + 1, h - 1), ix1 = min(ix + 1, w - 1);
+        float xl = (ox & 1) ? 0.5f : 0.f, yl = (oy & 1) ? 0.5f : 0.f;
+        float tl[8], tr[8], bl[8], br[8];
+        Elt<T>::load8(base + ((size_t)iy * w + ix) * is, tl);
+        Elt<T>::load8(base + ((size_t)iy * w + ix1) * is, tr);
+        Elt<T>::load8(base + ((size_t)iy1 * w + ix) * is, bl);
+        Elt<T>::load8(base + ((size_t)iy1 * w + ix1) * is, br);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float top = tl[i] + (tr[i] - tl[i]) * xl;
+            float bot = bl[i] + (br[i] - bl[i]) * xl;
+            r[i] = top + (bot - top) * yl;
+        }
+    }
+    Elt<T>::store8(out + (((size_t)b * 2 * h + oy) * 2 * w + ox) * os + g * 8, r);
+}
+
+hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s)
+{
+    size_t total = (size_t)in.n * 4 * in.h * in.w * (in.c / 8);
+    if (in.f32) hipLaunchKernelGGL(k_upsample2x<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, bilinear);
+    else hipLaunchKernelGGL(k_upsample2x<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, bilinear);
+    return hipGetLastError();
+}
+
+// ---- row M: max-pool, window origin -pad, out-of-range = -inf (DN/maxpool_layer.c:79-111 == TF) ----
+template <typename T>
+__global__ void k_maxpool(const T *in, int is, T *out, int os, int n, int h, int w, int ho, int wo, int c8,
+                          int size, int stride, int pad)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * ho * wo * c8;
+    if (idx >= total) return;
+    int g = (int)(idx % c8); size_t p = idx / c8;
+    int ox = (int)(p % wo); p /= wo;
+    int oy = (int)(p % ho); int b = (int)(p / ho);
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+    for (int dy = 0; dy < size; ++dy)
+        for (int dx = 0; dx < size; ++dx) {
+            int iy = oy * stride + dy - pad, ix = ox * stride + dx - pad;
+            if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) {
+                float v[8];
+                Elt<T>::load8(in + (((size_t)b * h + iy) * w + ix) * is + g * 8, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+            }
+        }
+    Elt<T>::store8(out + (((size_t)b * ho + oy) * wo + ox) * os + g * 8, m);
+}
+
+hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s)
+{
+    size_t total = (size_t)out.n * out.h * out.w * (in.c / 8);
+    if (in.f32) hipLaunchKernelGGL(k_maxpool<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, out.h, out.w, in.c / 8, size, stride, pad);
+    else hipLaunchKernelGGL(k_maxpool<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, out.h, out.w, in.c / 8, size, stride, pad);
+    return hipGetLastError();
+}
+
+// ---- row R: tf.space_to_depth (granule copy) or darknet reorg_cpu(forward=0) (element scramble) ----
+template <typename T>
+__global__ void k_space_to_depth(const T *in, int is, T *out, int os, int n, int h, int w, int c8, int st)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * h * w * c8;
+    if (idx >= total) return;
+    int g = (int)(idx % c8); size_t p = idx / c8;
+    int ix = (int)(p % w); p /= w;
+    int iy = (int)(p % h); int b = (int)(p / h);
+    float v[8];
+    Elt<T>::load8(in + (((size_t)b * h + iy) * w + ix) * is + g * 8, v);
+    int oy = iy / st, dy = iy - oy * st, ox = ix / st, dx = ix - ox * st;
+    int oc = (dy * st + dx) * (c8 * 8) + g * 8;
+    Elt<T>::store8(out + (((size_t)b * (h / st) + oy) * (w / st) + ox) * os + oc, v);
+}
+
+// Darknet: with x,out as NCHW flat buffers of the *input* geometry (w,h,c): out[in_index] = x[out_index]
+// (DN/blas.c:9-30, forward=0), the result then reinterpreted as [c*s*s, h/s, w/s].
+template <typename T>
+__global__ void k_reorg_darknet(const T *in, int is, T *out, int os, int n, int h, int w, int c, int st)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per = (size_t)h * w * c;
+    if (idx >= per * n) return;
+    int b = (int)(idx / per); int t = (int)(idx - (size_t)b * per);      // t = in_index
+    int i = t % w, j = (t / w) % h, k = t / (w * h);
+    int out_c = c / (st * st);
+    int c2 = k % out_c, off = k / out_c;
+    int w2 = i * st + off % st, h2 = j * st + off / st;
+    int src = w2 + w * st * (h2 + h * st * c2);                          // flat NCHW index into x viewed as [out_c, h*st, w*st]
+    // x is the input tensor [c, h, w] NCHW flat: decode src as (cs, ys, xs) of that geometry
+    int xs = src % w, ys = (src / w) % h, cs = src / (w * h);
+    float v = Elt<T>::load1(in + (((size_t)b * h + ys) * w + xs) * is + cs);
+    // destination flat index t of a buffer reinterpreted as [c*st*st, h/st, w/st]
+    int wo = w / st, ho = h / st;
+    int xo = t % wo, yo = (t / wo) % ho, co = t / (wo * ho);
+    Elt<T>::store1(out + (((size_t)b * ho + yo) * wo + xo) * os + co, v);
+}
+
+hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s)
+{
+    if (!darknet) {
+        size_t total = (size_t)in.n * in.h * in.w * (in.c / 8);
+        if (in.f32) hipLaunchKernelGGL(k_space_to_depth<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, stride);
+        else hipLaunchKernelGGL(k_space_to_depth<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, stride);
+    } else {
+        size_t total = (size_t)in.n * in.h * in.w * in.c;
+        if (in.f32) hipLaunchKernelGGL(k_reorg_darknet<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c, stride);
+        else hipLaunchKernelGGL(k_reorg_darknet<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c, stride);
+    }
+    return hipGetLastError();
+}
+
+// ---- rows B / Rt fallbacks: residual add and strided copy --------------------------------------
+template <typename T>
+__global__ void k_add(const T *a, int as, const T *b, int bs, T *o, int os, size_t npix, int c8)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8) return;
+    size_t p = idx / c8; int g = (int)(idx - p * c8);
+    float x[8], y[8];
+    Elt<T>::load8(a + p * as + g * 8, x);
+    Elt<T>::load8(b + p * bs + g * 8, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] += y[i];
+    Elt<T>::store8(o + p * os + g * 8, x);
+}
+hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s)
+{
+    size_t npix = (size_t)a.n * a.h * a.w; int c8 = a.c / 8;
+    if (a.f32) hipLaunchKernelGGL(k_add<float>, grid_for(npix * c8), dim3(256), 0, s, (const float *)a.ptr, a.stride, (const float *)b.ptr, b.stride, (float *)out.ptr, out.stride, npix, c8);
+    else hipLaunchKernelGGL(k_add<bf16_t>, grid_for(npix * c8), dim3(256), 0, s, (const bf16_t *)a.ptr, a.stride, (const bf16_t *)b.ptr, b.stride, (bf16_t *)out.ptr, out.stride, npix, c8);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_copy(const T *a, int as, T *o, int os, size_t npix, int c8)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8) return;
+    size_t p = idx / c8; int g = (int)(idx - p * c8);
+    float x[8];
+    Elt<T>::load8(a + p * as + g * 8, x);
+    Elt<T>::store8(o + p * os + g * 8, x);
+}
+hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s)
+{
+    size_t npix = (size_t)in.n * in.h * in.w; int c8 = in.c / 8;
+    if (in.f32) hipLaunchKernelGGL(k_copy<float>, grid_for(npix * c8), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, npix, c8);
+    else hipLaunchKernelGGL(k_copy<bf16_t>, grid_for(npix * c8), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, npix, c8);
+    return hipGetLastError();
+}
+
+// ---- dtype conversion between dense fp32 NHWC host-staging buffers and device views -------------
+template <typename T>
+__global__ void k_to_f32(const T *in, int is, float *out, size_t npix, int c)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c) return;
+    size_t p = idx / c; int ch = (int)(idx - p * c);
+    out[idx] = Elt<T>::load1(in + p * is + ch);
+}
+hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s)
+{
+    size_t npix = (size_t)in.n * in.h * in.w;
+    if (in.f32) hipLaunchKernelGGL(k_to_f32<float>, grid_for(npix * in.c), dim3(256), 0, s, (const float *)in.ptr, in.stride, out, npix, in.c);
+    else hipLaunchKernelGGL(k_to_f32<bf16_t>, grid_for(npix * in.c), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, out, npix, in.c);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_from_f32(const float *in, T *out, int os, size_t npix, int c)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c) return;
+    size_t p = idx / c; int ch = (int)(idx - p * c);
+    Elt<T>::store1(out + p * os + ch, in[idx]);
+}
+hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s)
+{
+    size_t npix = (size_t)out.n * out.h * out.w;
+    if (out.f32) hipLaunchKernelGGL(k_from_f32<float>, grid_for(npix * out.c), dim3(256), 0, s, in, (float *)out.ptr, out.stride, npix, out.c);
+    else hipLaunchKernelGGL(k_from_f32<bf16_t>, grid_for(npix * out.c), dim3(256), 0, s, in, (bf16_t *)out.ptr, out.stride, npix, out.c);
+    return hipGetLastError();
+}

@@ -1,0 +1,78 @@
+// Internal launcher interface between the host planner (yolo_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
+
+// A view of an NHWC activation tensor living inside a (possibly wider) buffer: pixel p, channel c is
+// at ptr[p * stride + c].  Concats are never materialised: producers write into a channel window of
+// the wider buffer (DESIGN.md "route/concat").
+struct TView {
+    void *ptr = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    int stride = 0;          // elements per pixel of the underlying buffer
+    int f32 = 0;             // element type: 0 bf16, 1 fp32
+};
+
+enum { ACT_LINEAR = 0, ACT_LEAKY = 1 };
+
+struct ConvArgs {
+    const void *in; int in_stride;       // elements per input pixel; Cin_pad channels are readable
+    const void *wt;                      // packed filters [Cout_pad][Kpad], K index = (kh*k+kw)*Cin_pad + c
+    const float *bias;                   // [Cout_pad] fp32 (BN folded)
+    void *out; int out_stride; int out_f32;
+    const void *res; int res_stride;     // residual (same type as in) or nullptr
+    int N, H, W, Cin_pad;
+    int Ho, Wo, Cout;
+    int ksize, stride, pad;
+    int Kpad;                            // multiple of 64
+    int act;
+    const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
+};
+
+// bf16 MFMA implicit-GEMM conv.  cfg in [0, conv_num_cfgs()); returns hipError.
+int conv_num_cfgs();
+const char *conv_cfg_name(int cfg);
+// rough preference used when no autotune ran
+int conv_pick_cfg(const ConvArgs &a);
+hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
+// exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
+hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
+
+// ---- memory-bound operators (ew_ops.hip) ------------------------------------------------------
+hipError_t launch_preprocess(const void *img, int fmt /*0 u8, 1 f32*/, int n, int hw, float scale,
+                             void *out, int out_f32, int out_stride, hipStream_t s);
+hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32,
+                            int out_stride, int out_c, hipStream_t s);
+hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s);
+hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s);
+hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s);
+hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s);
+hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s);
+hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s);   // dense NHWC fp32 copy
+hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s);
+
+// ---- head decode + postprocess (post_ops.hip) ---------------------------------------------------
+struct DecodeArgs {
+    const float *raw; int raw_stride;   // [n, g*g, raw_stride] fp32 head conv output
+    int n, g, na, classes;
+    float anchors[2 * 16];              // pixels (yolo) or grid units (region), masked order
+    int img_size;
+    int mode;                           // yolo_decode
+    int region;                         // 1: softmax/region head
+    float *det; int rows_total; int row_off;   // det [n, rows_total, 5+classes]
+};
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t s);
+
+struct PostArgs {
+    const float *det; int n, rows, attrs;
+    float score_thr, iou_thr; int max_out, nms_mode, select_mode;
+    int img_h, img_w;                   // V2 numpy flavour only: pixel box scaling (V2/utils.py:32-43); 0 = off
+    // workspace (device), sized for n images: scores/labels/cand/slabel/sscore [n*rows], sbox float4 [n*rows],
+    // keys u64 [n*rows_pow2]
+    float *scores; int *labels; int *cand; unsigned long long *keys; int rows_pow2;
+    float4 *sbox; int *slabel; float *sscore;
+    void *boxes_out; int *counts_out;   // yolo_box [n*max_out], int [n] (device)
+};
+hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);

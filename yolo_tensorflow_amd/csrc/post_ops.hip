@@ -1,0 +1,278 @@
+// Detection-head post-processing on the device (the reference has NO GPU kernel for this: darknet pulls
+// the head tensor to the host, DN/yolo_layer.c:347-362, and runs DN/box.c on the CPU; the TF scripts run
+// tf.boolean_mask / tf.image.non_max_suppression or pure-numpy loops, V3/yolo_v3.py:376-420).
+//
+//   k_decode_yolo / k_decode_region : rows D3 / D2 -- raw head conv output -> [n, rows, 5+C] fp32
+//   k_score_rows                    : row S        -- score = max_k(obj*cls_k), label = first argmax
+//   k_nms_image (1 workgroup/image) : rows S+N     -- order-preserving threshold compaction, sort by
+//                                     score (ties: lower row first), greedy suppression, top max_out
+//
+// Built with -ffp-contract=off: every IoU is evaluated with the reference's operation order in fp32
+// (or fp64 for the V2 numpy flavour) so the kept set is bit-identical to the oracle on equal inputs.
+#include "kernels.h"
+#include <math.h>
+
+struct BoxOut { float x0, y0, x1, y1, score; int cls; };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- D3: `_detection_layer` (V3/yolo_v3.py:111-159) / `_ratio_detection_layer` (V3/YOLOV3.py:168-238) ----
+__global__ void k_decode_yolo(const DecodeArgs a)
+{
+    const int attrs = 5 + a.classes;
+    const size_t total = (size_t)a.n * a.g * a.g * a.na * attrs;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int attr = (int)(idx % attrs); size_t box = idx / attrs;
+    int an = (int)(box % a.na); size_t t = box / a.na;
+    int cell = (int)(t % (a.g * a.g)); int b = (int)(t / (a.g * a.g));
+    float v = a.raw[((size_t)b * a.g * a.g + cell) * a.raw_stride + an * attrs + attr];
+    const int stride = a.img_size / a.g;
+    float r;
+    if (attr < 2) {
+        float off = (float)(attr == 0 ? cell % a.g : cell / a.g);
+        float s = sigmoidf_(v) + off;
+        r = a.mode == 0 ? s / (float)a.g : s * (float)stride;
+    } else if (attr < 4) {
+        float e = expf(v) * a.anchors[2 * an + (attr - 2)];       // anchors pre-divided by stride on the host
+        r = a.mode == 0 ? e / (float)a.g : e * (float)stride;
+    } else {
+        r = sigmoidf_(v);
+    }
+    a.det[((size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na + an) * attrs + attr] = r;
+}
+
+// ---- D2: V2 `decode` (V2/decode.py:13-47): sigmoid xy/obj, exp wh, softmax classes; stored as
+//      (bx, by, bw, bh, obj, cls...) normalised; corners are formed at selection time ----
+__global__ void k_decode_region(const DecodeArgs a)
+{
+    const int attrs = 5 + a.classes;
+    size_t box = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)a.n * a.g * a.g * a.na;
+    if (box >= total) return;
+    int an = (int)(box % a.na); size_t t = box / a.na;
+    int cell = (int)(t % (a.g * a.g)); int b = (int)(t / (a.g * a.g));
+    const float *p = a.raw + ((size_t)b * a.g * a.g + cell) * a.raw_stride + an * attrs;
+    float *o = a.det + ((size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na + an) * attrs;
+    const float G = (float)a.g;
+    o[0] = ((float)(cell % a.g) + sigmoidf_(p[0])) / G;
+    o[1] = ((float)(cell / a.g) + sigmoidf_(p[1])) / G;
+    o[2] = (a.anchors[2 * an] * expf(p[2])) / G;
+    o[3] = (a.anchors[2 * an + 1] * expf(p[3])) / G;
+    o[4] = sigmoidf_(p[4]);
+    float mx = -INFINITY;
+    for (int k = 0; k < a.classes; ++k) mx = fmaxf(mx, p[5 + k]);
+    float sum = 0.f;
+    for (int k = 0; k < a.classes; ++k) sum += expf(p[5 + k] - mx);
+    for (int k = 0; k < a.classes; ++k) o[5 + k] = expf(p[5 + k] - mx) / sum;
+}
+
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.region) {
+        size_t total = (size_t)a.n * a.g * a.g * a.na;
+        hipLaunchKernelGGL(k_decode_region, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, a);
+    } else {
+        size_t total = (size_t)a.n * a.g * a.g * a.na * (5 + a.classes);
+        hipLaunchKernelGGL(k_decode_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// ---- S: box_scores = confidence * class_prob; argmax / reduce_max (V3/YOLOV3.py:353-357) ----
+__global__ void k_score_rows(const float *det, size_t nrows, int attrs, float *scores, int *labels)
+{
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const float *p = det + r * attrs;
+    const float obj = p[4];
+    float best = -INFINITY; int bi = 0;
+    for (int k = 0; k < attrs - 5; ++k) {
+        float s = obj * p[5 + k];
+        if (s > best) { best = s; bi = k; }         // first maximum, like argmax
+    }
+    scores[r] = best; labels[r] = bi;
+}
+
+// TF NonMaxSuppression IOU on [y0,x0,y1,x1] rows (min/max-normalised corners, 0 when an area <= 0)
+__device__ __forceinline__ float iou_tf(float4 a, float4 b)   // a,b = (x0,y0,x1,y1)
+{
+    float ymin_i = fminf(a.y, a.w), xmin_i = fminf(a.x, a.z), ymax_i = fmaxf(a.y, a.w), xmax_i = fmaxf(a.x, a.z);
+    float ymin_j = fminf(b.y, b.w), xmin_j = fminf(b.x, b.z), ymax_j = fmaxf(b.y, b.w), xmax_j = fmaxf(b.x, b.z);
+    float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.f || area_j <= 0.f) return 0.f;
+    float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+    float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+    float inter = fmaxf(iy1 - iy0, 0.f) * fmaxf(ix1 - ix0, 0.f);
+    return inter / ((area_i + area_j) - inter);
+}
+// V2/utils.py:155-174 on int32 pixel boxes: int arithmetic for the areas, float64 for the ratio
+__device__ __forceinline__ double iou_v2np(int4 a, int4 b)     // (x0,y0,x1,y1) ints; the reference names them ymin.. but is symmetric
+{
+    int i0 = max(a.x, b.x), i1 = max(a.y, b.y), i2 = min(a.z, b.z), i3 = min(a.w, b.w);
+    double ih = fmax((double)(i2 - i0), 0.), iw = fmax((double)(i3 - i1), 0.);
+    double iv = ih * iw;
+    int v1 = (a.z - a.x) * (a.w - a.y), v2 = (b.z - b.x) * (b.w - b.y);
+    return iv / ((double)(v1 + v2) - iv);
+}
+// darknet box_iou (DN/box.c:152-182) on (cx,cy,w,h)
+__device__ __forceinline__ float dn_overlap(float x1, float w1, float x2, float w2)
+{
+    float l1 = x1 - w1 / 2, l2 = x2 - w2 / 2;
+    float left = l1 > l2 ? l1 : l2;
+    float r1 = x1 + w1 / 2, r2 = x2 + w2 / 2;
+    float right = r1 < r2 ? r1 : r2;
+    return right - left;
+}
+__device__ __forceinline__ float iou_darknet(float4 a, float4 b)
+{
+    float w = dn_overlap(a.x, a.z, b.x, b.z), h = dn_overlap(a.y, a.w, b.y, b.w);
+    float inter = (w < 0 || h < 0) ? 0.f : w * h;
+    float uni = a.z * a.w + b.z * b.w - inter;
+    return inter / uni;
+}
+
+#define NMS_THREADS 1024
+#define SORT_LDS 4096
+
+__global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
+{
+    float4 *sbox = a.sbox; int *slabel = a.slabel; float *sscore = a.sscore;
+    const int img_h = a.img_h, img_w = a.img_w;
+    __shared__ unsigned long long skeys[SORT_LDS];
+    __shared__ unsigned int alive[1024];           // bitset for up to 32768 candidates
+    __shared__ int wave_cnt[NMS_THREADS / 64];
+    __shared__ int s_base, s_cur, s_kept;
+
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *scores = a.scores + (size_t)img * a.rows;
+    const int *labels = a.labels + (size_t)img * a.rows;
+    int *cand = a.cand + (size_t)img * a.rows;
+    unsigned long long *gkeys = a.keys + (size_t)img * a.rows_pow2;
+    sbox += (size_t)img * a.rows; slabel += (size_t)img * a.rows; sscore += (size_t)img * a.rows;
+    BoxOut *out = (BoxOut *)a.boxes_out + (size_t)img * a.max_out;
+
+    // (1) order-preserving compaction of rows whose score passes the threshold (tf.boolean_mask order)
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < a.rows; r0 += NMS_THREADS) {
+        int r = r0 + tid;
+        bool f = false;
+        if (r < a.rows) { float s = scores[r]; f = a.select_mode == 0 ? (s > a.score_thr) : (s >= a.score_thr); }
+        unsigned long long m = __ballot(f);
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int i = 0; i < NMS_THREADS / 64; ++i) { int c = wave_cnt[i]; if (i < wv) pre += c; tot += c; }
+        int base = s_base;
+        if (f) cand[base + pre + __popcll(m & ((1ull << lane) - 1))] = r;
+        __syncthreads();
+        if (tid == 0) s_base = base + tot;
+        __syncthreads();
+    }
+    int M = s_base;
+    // V2 numpy flavour keeps only the 400 best before NMS (bboxes_sort top_k, V2/utils.py:146-151)
+    int P = 1; while (P < M) P <<= 1;
+    const bool in_lds = P <= SORT_LDS;
+    unsigned long long *keys = in_lds ? skeys : gkeys;
+
+    // (2) keys: descending score, ascending candidate index
+    for (int i = tid; i < P; i += NMS_THREADS) {
+        unsigned long long k = ~0ull;
+        if (i < M) {
+            unsigned int u = __float_as_uint(scores[cand[i]]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone map of float order
+            k = ((unsigned long long)(~u) << 32) | (unsigned int)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    // (3) bitonic sort, ascending
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += NMS_THREADS) {
+                int x = i ^ j;
+                if (x > i) {
+                    unsigned long long ki = keys[i], kx = keys[x];
+                    bool up = (i & k) == 0;
+                    if ((ki > kx) == up) { keys[i] = kx; keys[x] = ki; }
+                }
+            }
+            __syncthreads();
+        }
+    if (a.nms_mode == 1 && M > 400) M = 400;
+    // (4) gather candidates in sorted order
+    for (int i = tid; i < M; i += NMS_THREADS) {
+        int row = cand[(unsigned int)(keys[i] & 0xffffffffu)];
+        const float *p = a.det + ((size_t)img * a.rows + row) * a.attrs;
+        float4 b;
+        if (a.nms_mode == 2) b = float4{p[0], p[1], p[2], p[3]};                       // (cx,cy,w,h)
+        else {
+            float w2 = p[2] * 0.5f, h2 = p[3] * 0.5f;                                      // V3/YOLOV3.py:348-351
+            b = float4{p[0] - w2, p[1] - h2, p[0] + w2, p[1] + h2};
+        }
+        if (a.nms_mode == 1 && img_w > 0) {
+            // V2/utils.py:32-43: scale to the image, truncate to int32, clip to [0, w-1] x [0, h-1]
+            int x0 = (int)(b.x * (float)img_w), y0 = (int)(b.y * (float)img_h);
+            int x1 = (int)(b.z * (float)img_w), y1 = (int)(b.w * (float)img_h);
+            x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, img_w - 1); y1 = min(y1, img_h - 1);
+            b = float4{(float)x0, (float)y0, (float)x1, (float)y1};
+        }
+        sbox[i] = b; slabel[i] = labels[row]; sscore[i] = scores[row];
+    }
+    for (int i = tid; i < 1024; i += NMS_THREADS) {
+        int lo = i * 32;
+        unsigned int bits = 0;
+        if (lo < M) bits = (M - lo >= 32) ? 0xffffffffu : ((1u << (M - lo)) - 1u);
+        alive[i] = bits;
+    }
+    if (tid == 0) { s_cur = -1; s_kept = 0; }
+    __syncthreads();
+
+    // (5) greedy: the best alive candidate is kept and suppresses every later one it overlaps
+    int pos = 0;
+    while (true) {
+        if (tid == 0) {
+            int cur = -1;
+            for (int wd = pos >> 5; wd < ((M + 31) >> 5); ++wd) {
+                unsigned int bits = alive[wd];
+                if (wd == (pos >> 5)) bits &= ~((1u << (pos & 31)) - 1u);
+                if (bits) { cur = wd * 32 + __ffs(bits) - 1; break; }
+            }
+            s_cur = cur;
+        }
+        __syncthreads();
+        const int cur = s_cur, kept = s_kept;
+        if (cur < 0 || (a.nms_mode == 0 && kept >= a.max_out)) break;
+        const float4 bc = sbox[cur];
+        const int lc = slabel[cur];
+        if (tid == 0) {
+            if (kept < a.max_out) out[kept] = BoxOut{bc.x, bc.y, bc.z, bc.w, sscore[cur], lc};
+            s_kept = kept + 1;
+        }
+        for (int j = cur + 1 + tid; j < M; j += NMS_THREADS) {
+            if (!((alive[j >> 5] >> (j & 31)) & 1u)) continue;
+            bool kill;
+            if (a.nms_mode == 0) kill = iou_tf(bc, sbox[j]) > a.iou_thr;
+            else if (a.nms_mode == 2) kill = slabel[j] == lc && iou_darknet(bc, sbox[j]) > a.iou_thr;
+            else {
+                float4 bj = sbox[j];
+                double v = iou_v2np(int4{(int)bc.x, (int)bc.y, (int)bc.z, (int)bc.w}, int4{(int)bj.x, (int)bj.y, (int)bj.z, (int)bj.w});
+                kill = slabel[j] == lc && !(v < (double)a.iou_thr);
+            }
+            if (kill) atomicAnd(&alive[j >> 5], ~(1u << (j & 31)));
+        }
+        pos = cur + 1;
+        __syncthreads();
+    }
+    if (tid == 0) a.counts_out[img] = min(s_kept, a.max_out);
+}
+
+hipError_t launch_postprocess(const PostArgs &a, hipStream_t s)
+{
+    size_t nrows = (size_t)a.n * a.rows;
+    hipLaunchKernelGGL(k_score_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, a.det, nrows, a.attrs, a.scores, a.labels);
+    hipLaunchKernelGGL(k_nms_image, dim3(a.n), dim3(NMS_THREADS), 0, s, a);
+    return hipGetLastError();
+}

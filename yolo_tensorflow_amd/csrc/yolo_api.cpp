@@ -1,0 +1,870 @@
+// Host side of libyolo_hip.so: darknet-cfg planner, BN-fold + filter packing, launch sequence, C ABI.
+//
+// What the reference does with a Python graph builder + tf.Session (V3/yolo_v3.py:195-267,
+// D2T/YOLO_V3_convert_darkenet_to_Tensorflow.py:435-545) or with parse_network_cfg + forward_network
+// (DN/parser.c:730-875, DN/network.c:188-211) is done here once at yolo_create():
+//   * shapes are inferred, every layer gets a view into a small pool of HBM buffers (liveness-based
+//     reuse so consecutive layers recycle the same few allocations and stay in L2 / Infinity Cache);
+//   * route/concat is never executed: producers are planned to write straight into a channel window of
+//     the concat buffer (DN/route_layer.c:74-89 and tf.concat V3/yolo_v3.py:247,259 become strides);
+//   * `shortcut` after a conv is folded into that conv's epilogue (V3/yolo_v3.py:54-60);
+//   * batch-norm is folded into the filters at weight-load time.
+#include "../../include/yolo_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum LType { L_CONV, L_SHORTCUT, L_ROUTE, L_UPSAMPLE, L_MAXPOOL, L_REORG, L_YOLO, L_REGION };
+
+struct Section { std::string type; std::map<std::string, std::string> kv; };
+
+struct Layer {
+    LType type;
+    int H = 0, W = 0, C = 0;             // logical output geometry
+    std::vector<int> in;                 // producer layer indices (-1 = network input)
+    // conv
+    int filters = 0, size = 0, stride = 1, pad = 0, bn = 0, act = ACT_LINEAR;
+    int cin = 0, cin_pad = 0, kpad = 0, cout_pad = 0;
+    void *d_w = nullptr; float *d_b = nullptr;
+    int tile_cfg = -1;
+    int residual_from = -2;              // >= -1: fused shortcut source
+    bool head = false;                   // conv feeding a yolo/region layer: fp32 output
+    // shortcut/route bookkeeping
+    bool noop = false;                   // output is an alias / was produced by someone else
+    std::vector<int> copy_inputs;        // route inputs that must be copied (could not be placed)
+    std::vector<int> copy_offsets;
+    // pool / upsample / reorg
+    int psize = 0, pstride = 0, ppad = 0;
+    // head
+    int na = 0, classes = 0, row_off = 0;
+    std::vector<float> anchors;          // masked, in reference units
+    // storage
+    int storage = -1; int ch_off = 0;    // view = storage buffer + channel offset
+    TView out;
+};
+
+struct Storage { int def = 1 << 30, last = -1; size_t bytes = 0; int phys = -1; int stride = 0; bool f32 = false; bool persistent = false; };
+
+}  // namespace
+
+struct yolo_ctx {
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int max_batch = 1, dtype = YOLO_BF16, semantics = YOLO_SEM_TF, decode = YOLO_DECODE_RATIO, keep_layers = 0;
+    int in_h = 0, in_w = 0, in_c = 0;
+    std::vector<Layer> layers;
+    std::vector<Storage> storages;
+    std::vector<void *> phys; std::vector<size_t> phys_bytes;
+    TView input;                          // [n, S, S, 8]
+    void *d_zeros = nullptr;
+    void *d_stage = nullptr; size_t stage_bytes = 0;     // host->device image staging
+    float *d_det = nullptr; int rows = 0, attrs = 0;
+    // postprocess workspace
+    float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
+    float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
+    void *d_boxes = nullptr; int *d_counts = nullptr; int boxes_cap = 0;
+    bool weights_loaded = false;
+    size_t weights_count = 0;
+    double conv_flops = 0;
+    int last_n = 0;
+    bool elem_f32() const { return dtype == YOLO_FP32; }
+    size_t esize() const { return dtype == YOLO_FP32 ? 4 : 2; }
+};
+
+namespace {
+
+int fail(yolo_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCK(c, expr)                                                                       \
+    do { hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(c, YOLO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+uint16_t f2bf(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---- cfg parsing (DN/parser.c:730-875 read_cfg + option_find_*) ------------------------------
+bool parse_cfg(const char *text, std::vector<Section> &out, std::string &err)
+{
+    std::string s(text ? text : "");
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        size_t e = s.find('\n', pos); if (e == std::string::npos) e = s.size();
+        std::string line = s.substr(pos, e - pos); pos = e + 1;
+        size_t a = line.find_first_not_of(" \t\r"); if (a == std::string::npos) continue;
+        size_t b = line.find_last_not_of(" \t\r"); line = line.substr(a, b - a + 1);
+        if (line[0] == '#' || line[0] == ';') continue;
+        if (line[0] == '[') {
+            size_t r = line.find(']'); if (r == std::string::npos) { err = "cfg: unterminated section " + line; return false; }
+            Section sec; sec.type = line.substr(1, r - 1); out.push_back(sec);
+        } else {
+            size_t eq = line.find('='); if (eq == std::string::npos || out.empty()) { err = "cfg: bad line '" + line + "'"; return false; }
+            std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+            auto trim = [](std::string &t) { size_t x = t.find_first_not_of(" \t"); size_t y = t.find_last_not_of(" \t"); t = x == std::string::npos ? "" : t.substr(x, y - x + 1); };
+            trim(k); trim(v); out.back().kv[k] = v;
+        }
+    }
+    if (out.empty() || (out[0].type != "net" && out[0].type != "network")) { err = "cfg: first section must be [net]"; return false; }
+    return true;
+}
+int opt_i(const Section &s, const char *k, int d) { auto it = s.kv.find(k); return it == s.kv.end() ? d : atoi(it->second.c_str()); }
+std::string opt_s(const Section &s, const char *k, const char *d) { auto it = s.kv.find(k); return it == s.kv.end() ? std::string(d) : it->second; }
+std::vector<float> opt_list(const Section &s, const char *k)
+{
+    std::vector<float> v; auto it = s.kv.find(k); if (it == s.kv.end()) return v;
+    const char *p = it->second.c_str();
+    while (*p) { char *e; double d = strtod(p, &e); if (e == p) break; v.push_back((float)d); p = e; while (*p == ',' || *p == ' ') ++p; }
+    return v;
+}
+
+TView view_of(const yolo_ctx *c, int idx) { return idx < 0 ? c->input : c->layers[idx].out; }
+
+int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
+{
+    const Section &net = secs[0];
+    c->in_h = opt_i(net, "height", 0); c->in_w = opt_i(net, "width", 0); c->in_c = opt_i(net, "channels", 3);
+    if (c->in_h <= 0 || c->in_w != c->in_h || c->in_c != 3)
+        return fail(c, YOLO_ERR_UNSUPPORTED, "cfg: need square input with 3 channels (got %dx%dx%d)", c->in_w, c->in_h, c->in_c);
+    const int NL = (int)secs.size() - 1;
+    c->layers.resize(NL);
+    int H = c->in_h, W = c->in_w, C = c->in_c;
+    auto dims = [&](int idx, int &h, int &w, int &ch) { if (idx < 0) { h = c->in_h; w = c->in_w; ch = c->in_c; } else { h = c->layers[idx].H; w = c->layers[idx].W; ch = c->layers[idx].C; } };
+    c->rows = 0; c->attrs = 0; c->conv_flops = 0; c->weights_count = 0;
+    for (int i = 0; i < NL; ++i) {
+        const Section &s = secs[i + 1]; Layer &L = c->layers[i];
+        L.in = {i - 1};
+        if (s.type == "convolutional") {
+            L.type = L_CONV; L.filters = opt_i(s, "filters", 1); L.size = opt_i(s, "size", 1); L.stride = opt_i(s, "stride", 1);
+            L.pad = opt_i(s, "pad", 0) ? L.size / 2 : opt_i(s, "padding", 0);
+            L.bn = opt_i(s, "batch_normalize", 0);
+            std::string act = opt_s(s, "activation", "logistic");
+            if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
+            else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
+            if (L.size != 1 && L.size != 3) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: conv size %d unsupported on the device path", i, L.size);
+            L.cin = C; L.cin_pad = roundup(C, 8);
+            L.kpad = roundup(L.size * L.size * L.cin_pad, 64); L.cout_pad = roundup(L.filters, 256);
+            H = (H + 2 * L.pad - L.size) / L.stride + 1; W = (W + 2 * L.pad - L.size) / L.stride + 1; C = L.filters;
+            c->conv_flops += 2.0 * L.size * L.size * L.cin * L.filters * (double)H * W;
+            c->weights_count += (size_t)L.filters * (L.bn ? 4 : 1) + (size_t)L.filters * L.cin * L.size * L.size;
+        } else if (s.type == "shortcut") {
+            L.type = L_SHORTCUT; int f = opt_i(s, "from", -1); f = f < 0 ? i + f : f;
+            if (f < 0 || f >= i) return fail(c, YOLO_ERR_INVALID, "layer %d: bad shortcut from", i);
+            L.in = {i - 1, f};
+            if (opt_s(s, "activation", "linear") != "linear") return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: shortcut activation", i);
+            int h2, w2, c2; dims(f, h2, w2, c2);
+            if (h2 != H || w2 != W || c2 != C) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: shortcut shape mismatch", i);
+        } else if (s.type == "route") {
+            L.type = L_ROUTE; L.in.clear();
+            std::vector<float> ls = opt_list(s, "layers");
+            if (ls.empty()) return fail(c, YOLO_ERR_INVALID, "layer %d: route without layers", i);
+            C = 0;
+            for (float v : ls) {
+                int l = (int)v; l = l < 0 ? i + l : l;
+                if (l < 0 || l >= i) return fail(c, YOLO_ERR_INVALID, "layer %d: bad route index", i);
+                L.in.push_back(l);
+                int h2, w2, c2; dims(l, h2, w2, c2);
+                if (L.in.size() == 1) { H = h2; W = w2; } else if (h2 != H || w2 != W) return fail(c, YOLO_ERR_INVALID, "layer %d: route spatial mismatch", i);
+                C += c2;
+            }
+        } else if (s.type == "upsample") {
+            L.type = L_UPSAMPLE; L.pstride = opt_i(s, "stride", 2);
+            if (L.pstride != 2) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: upsample stride %d", i, L.pstride);
+            H *= 2; W *= 2;
+        } else if (s.type == "maxpool") {
+            L.type = L_MAXPOOL; L.pstride = opt_i(s, "stride", 1); L.psize = opt_i(s, "size", L.pstride);
+            L.ppad = opt_i(s, "padding", (L.psize - 1) / 2);
+            H = (H + 2 * L.ppad) / L.pstride; W = (W + 2 * L.ppad) / L.pstride;
+        } else if (s.type == "reorg") {
+            L.type = L_REORG; L.pstride = opt_i(s, "stride", 1);
+            if (H % L.pstride || W % L.pstride) return fail(c, YOLO_ERR_INVALID, "layer %d: reorg stride", i);
+            H /= L.pstride; W /= L.pstride; C *= L.pstride * L.pstride;
+        } else if (s.type == "yolo" || s.type == "region") {
+            L.type = s.type == "yolo" ? L_YOLO : L_REGION;
+            L.classes = opt_i(s, "classes", 20);
+            std::vector<float> an = opt_list(s, "anchors"), mask = opt_list(s, "mask");
+            int total = opt_i(s, "num", 1);
+            if ((int)an.size() < 2 * total) return fail(c, YOLO_ERR_INVALID, "layer %d: anchors/num mismatch", i);
+            if (L.type == L_YOLO && !mask.empty()) { for (float m : mask) { int k = (int)m; if (k < 0 || k >= total) return fail(c, YOLO_ERR_INVALID, "layer %d: mask", i); L.anchors.push_back(an[2 * k]); L.anchors.push_back(an[2 * k + 1]); } }
+            else L.anchors.assign(an.begin(), an.begin() + 2 * total);
+            L.na = (int)L.anchors.size() / 2;
+            if (L.na > 16) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: more than 16 anchors", i);
+            if (i == 0 || c->layers[i - 1].type != L_CONV) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: head must follow a conv", i);
+            if (C != L.na * (5 + L.classes)) return fail(c, YOLO_ERR_INVALID, "layer %d: head expects %d channels, conv gives %d", i, L.na * (5 + L.classes), C);
+            if (H != W) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: non-square grid", i);
+            if (c->attrs && c->attrs != 5 + L.classes) return fail(c, YOLO_ERR_UNSUPPORTED, "heads with different class counts");
+            c->attrs = 5 + L.classes; L.row_off = c->rows; c->rows += H * W * L.na;
+            c->layers[i - 1].head = true;
+        } else {
+            return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: section [%s] is outside the inference hot path", i, s.type.c_str());
+        }
+        L.H = H; L.W = W; L.C = C;
+    }
+    if (c->rows == 0) return fail(c, YOLO_ERR_INVALID, "cfg has no [yolo]/[region] head");
+    if (c->rows > 32768) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 32768 candidates per image");
+
+    // ---- use counts, shortcut fusion, concat placement ----
+    std::vector<int> uses(NL, 0);
+    for (int i = 0; i < NL; ++i) for (int j : c->layers[i].in) if (j >= 0) uses[j]++;
+    for (int i = 0; i < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.type == L_SHORTCUT && !c->keep_layers) {
+            Layer &P = c->layers[i - 1];
+            if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1) { P.residual_from = L.in[1]; L.noop = true; }
+        }
+    }
+    // storage assignment: st_of[i] = storage holding layer i's output
+    std::vector<int> place_route(NL, -1), place_off(NL, 0);
+    for (int i = 0; i < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.type != L_ROUTE || L.in.size() < 2) continue;
+        int off = 0;
+        for (int j : L.in) {
+            int cj = j < 0 ? c->in_c : c->layers[j].C;
+            bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
+                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && (cj % 8 == 0) && (off % 8 == 0);
+            // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
+            if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
+            if (ok) { place_route[j] = i; place_off[j] = off; }
+            else { L.copy_inputs.push_back(j); L.copy_offsets.push_back(off); }
+            off += cj;
+        }
+    }
+    auto new_storage = [&](int stride, bool f32, size_t pixels, bool persistent) {
+        Storage s; s.stride = stride; s.f32 = f32; s.bytes = pixels * (size_t)stride * (f32 ? 4 : c->esize()); s.persistent = persistent;
+        c->storages.push_back(s); return (int)c->storages.size() - 1;
+    };
+    // routes first (so producers can point into them)
+    for (int i = 0; i < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.type == L_ROUTE && L.in.size() >= 2) {
+            L.storage = new_storage(roundup(L.C, 8), c->elem_f32(), (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+        }
+    }
+    for (int i = 0; i < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.type == L_YOLO || L.type == L_REGION) { L.noop = true; L.storage = c->layers[i - 1].storage; L.ch_off = c->layers[i - 1].ch_off; continue; }
+        if (L.type == L_ROUTE && L.in.size() == 1) { L.noop = true; int j = L.in[0]; if (j < 0) return fail(c, YOLO_ERR_UNSUPPORTED, "route to network input"); L.storage = c->layers[j].storage; L.ch_off = c->layers[j].ch_off; continue; }
+        if (L.type == L_ROUTE) continue;
+        if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
+        else if (L.head) L.storage = new_storage(roundup(L.C, 4), true, (size_t)c->max_batch * L.H * L.W, true);
+        else L.storage = new_storage(roundup(L.C, 8), c->elem_f32(), (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+    }
+    // a conv whose shortcut was fused writes the shortcut layer's tensor
+    for (int i = 0; i + 1 < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.type == L_CONV && L.residual_from >= -1) {
+            // its own storage slot is unused: redirect to the shortcut's
+            Storage &mine = c->storages[L.storage];
+            if (place_route[i] < 0) mine.bytes = 0;
+            L.storage = c->layers[i + 1].storage; L.ch_off = c->layers[i + 1].ch_off;
+        }
+    }
+    // liveness: def = first writer, last = last reader of any view
+    for (int i = 0; i < NL; ++i) {
+        Layer &L = c->layers[i];
+        if (L.storage < 0) continue;
+        if (!L.noop) { Storage &s = c->storages[L.storage]; s.def = std::min(s.def, i); s.last = std::max(s.last, i); }
+        for (int j : L.in) if (j >= 0) { Storage &s = c->storages[c->layers[j].storage]; s.last = std::max(s.last, i); }
+        if (L.type == L_CONV && L.residual_from >= 0) { Storage &s = c->storages[c->layers[L.residual_from].storage]; s.last = std::max(s.last, i); }
+    }
+    // greedy pooled assignment
+    std::vector<int> free_list;
+    for (int i = 0; i < NL; ++i) {
+        for (size_t k = 0; k < c->storages.size(); ++k) {
+            Storage &s = c->storages[k];
+            if (s.def != i || s.bytes == 0) continue;
+            int pick = -1;
+            if (!s.persistent) {
+                for (size_t f = 0; f < free_list.size(); ++f)
+                    if (pick < 0 || c->phys_bytes[free_list[f]] > c->phys_bytes[free_list[pick]]) pick = (int)f;
+            }
+            if (pick >= 0) { s.phys = free_list[pick]; free_list.erase(free_list.begin() + pick); c->phys_bytes[s.phys] = std::max(c->phys_bytes[s.phys], s.bytes); }
+            else { s.phys = (int)c->phys_bytes.size(); c->phys_bytes.push_back(s.bytes); }
+        }
+        for (size_t k = 0; k < c->storages.size(); ++k) {
+            Storage &s = c->storages[k];
+            if (s.last == i && s.phys >= 0 && !s.persistent) free_list.push_back(s.phys);
+        }
+    }
+    return YOLO_OK;
+}
+
+int allocate(yolo_ctx *c)
+{
+    c->phys.assign(c->phys_bytes.size(), nullptr);
+    for (size_t i = 0; i < c->phys_bytes.size(); ++i) {
+        HIPCK(c, hipMalloc(&c->phys[i], c->phys_bytes[i] + 256));
+        HIPCK(c, hipMemsetAsync(c->phys[i], 0, c->phys_bytes[i] + 256, c->stream));
+    }
+    for (auto &L : c->layers) {
+        if (L.storage < 0) continue;
+        Storage &s = c->storages[L.storage];
+        if (s.phys < 0) return fail(c, YOLO_ERR_STATE, "internal: storage without buffer");
+        L.out.n = c->max_batch; L.out.h = L.H; L.out.w = L.W; L.out.c = L.C; L.out.stride = s.stride; L.out.f32 = s.f32;
+        L.out.ptr = (char *)c->phys[s.phys] + (size_t)L.ch_off * (s.f32 ? 4 : c->esize());
+    }
+    // network input: 3 real channels padded to 8
+    size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 8 * c->esize();
+    HIPCK(c, hipMalloc(&c->input.ptr, in_bytes));
+    c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8; c->input.f32 = c->elem_f32();
+    HIPCK(c, hipMalloc(&c->d_zeros, 4096)); HIPCK(c, hipMemsetAsync(c->d_zeros, 0, 4096, c->stream));
+    c->stage_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 3 * 4;
+    HIPCK(c, hipMalloc(&c->d_stage, c->stage_bytes));
+    size_t nr = (size_t)c->max_batch * c->rows;
+    HIPCK(c, hipMalloc((void **)&c->d_det, nr * c->attrs * 4));
+    c->rows_pow2 = 1; while (c->rows_pow2 < c->rows) c->rows_pow2 <<= 1;
+    HIPCK(c, hipMalloc((void **)&c->d_scores, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_labels, nr * 4));
+    HIPCK(c, hipMalloc((void **)&c->d_cand, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_keys, (size_t)c->max_batch * c->rows_pow2 * 8));
+    HIPCK(c, hipMalloc((void **)&c->d_sbox, nr * 16)); HIPCK(c, hipMalloc((void **)&c->d_slabel, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_sscore, nr * 4));
+    HIPCK(c, hipMalloc((void **)&c->d_counts, (size_t)c->max_batch * 4));
+    // filters
+    for (auto &L : c->layers) if (L.type == L_CONV) {
+        size_t wb = (size_t)L.cout_pad * L.kpad * c->esize();
+        HIPCK(c, hipMalloc(&L.d_w, wb)); HIPCK(c, hipMemsetAsync(L.d_w, 0, wb, c->stream));
+        HIPCK(c, hipMalloc((void **)&L.d_b, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_b, 0, (size_t)L.cout_pad * 4, c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return YOLO_OK;
+}
+
+ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
+{
+    ConvArgs a; memset(&a, 0, sizeof a);
+    TView in = view_of(c, L.in[0]);
+    a.in = in.ptr; a.in_stride = in.stride; a.wt = L.d_w; a.bias = L.d_b;
+    a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_f32 = L.out.f32;
+    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
+    a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
+    a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = L.act; a.zeros = c->d_zeros;
+    return a;
+}
+
+int run_layer(yolo_ctx *c, int i, int n)
+{
+    Layer &L = c->layers[i];
+    hipStream_t s = c->stream;
+    auto nview = [&](TView v) { v.n = n; return v; };
+    switch (L.type) {
+    case L_CONV: {
+        ConvArgs a = conv_args(c, L, n);
+        if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
+        else { int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a); HIPCK(c, launch_conv_bf16(a, cfg, s)); }
+        break; }
+    case L_SHORTCUT:
+        if (!L.noop) HIPCK(c, launch_add(nview(view_of(c, L.in[0])), nview(view_of(c, L.in[1])), nview(L.out), s));
+        break;
+    case L_ROUTE:
+        for (size_t k = 0; k < L.copy_inputs.size(); ++k) {
+            TView src = nview(view_of(c, L.copy_inputs[k])); TView dst = nview(L.out);
+            dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * c->esize(); dst.c = src.c;
+            if (src.c % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of %d channels", src.c);
+            HIPCK(c, launch_copy(src, dst, s));
+        }
+        break;
+    case L_UPSAMPLE: HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
+    case L_MAXPOOL: HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
+    case L_REORG: HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
+    case L_YOLO: case L_REGION: {
+        DecodeArgs d; memset(&d, 0, sizeof d);
+        const Layer &P = c->layers[i - 1];
+        d.raw = (const float *)P.out.ptr; d.raw_stride = P.out.stride; d.n = n; d.g = L.H; d.na = L.na; d.classes = L.classes;
+        d.img_size = c->in_h; d.mode = c->decode; d.region = L.type == L_REGION;
+        const int stride = c->in_h / L.H;
+        for (int k = 0; k < 2 * L.na; ++k)
+            d.anchors[k] = L.type == L_YOLO ? (float)(1.0 * (double)L.anchors[k] / (double)stride) : L.anchors[k];
+        d.det = c->d_det; d.rows_total = c->rows; d.row_off = L.row_off;
+        HIPCK(c, launch_decode(d, s));
+        break; }
+    }
+    return YOLO_OK;
+}
+
+int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale)
+{
+    if (n < 1 || n > c->max_batch) return fail(c, YOLO_ERR_INVALID, "batch %d outside 1..%d", n, c->max_batch);
+    if (!images) return fail(c, YOLO_ERR_INVALID, "images == NULL");
+    size_t npix = (size_t)n * c->in_h * c->in_w;
+    const void *src = images;
+    if (loc == YOLO_HOST) {
+        HIPCK(c, hipMemcpyAsync(c->d_stage, images, npix * 3 * (fmt == YOLO_IMG_U8 ? 1 : 4), hipMemcpyHostToDevice, c->stream));
+        src = c->d_stage;
+    }
+    HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.f32, 8, c->stream));
+    return YOLO_OK;
+}
+
+int run_network(yolo_ctx *c, int n)
+{
+    for (int i = 0; i < (int)c->layers.size(); ++i) { int r = run_layer(c, i, n); if (r) return r; }
+    c->last_n = n;
+    return YOLO_OK;
+}
+
+int copy_out(yolo_ctx *c, void *dst, const void *src, size_t bytes, int loc)
+{
+    if (loc == YOLO_HOST) { HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream)); }
+    else HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return YOLO_OK;
+}
+
+int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out,
+         int nms_mode, int select_mode, int img_h, int img_w, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+{
+    if (max_out < 1) return fail(c, YOLO_ERR_INVALID, "max_out < 1");
+    if (nms_mode < 0 || nms_mode > 2 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
+    size_t need = (size_t)n * max_out;
+    if ((int)need > c->boxes_cap) {
+        if (c->d_boxes) HIPCK(c, hipFree(c->d_boxes));
+        HIPCK(c, hipMalloc(&c->d_boxes, need * sizeof(yolo_box))); c->boxes_cap = (int)need;
+    }
+    PostArgs p; memset(&p, 0, sizeof p);
+    p.det = det; p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_out;
+    p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w;
+    p.scores = c->d_scores; p.labels = c->d_labels; p.cand = c->d_cand; p.keys = c->d_keys; p.rows_pow2 = c->rows_pow2;
+    p.sbox = c->d_sbox; p.slabel = c->d_slabel; p.sscore = c->d_sscore; p.boxes_out = c->d_boxes; p.counts_out = c->d_counts;
+    HIPCK(c, hipMemsetAsync(c->d_boxes, 0, need * sizeof(yolo_box), c->stream));
+    HIPCK(c, launch_postprocess(p, c->stream));
+    if (boxes_out) { int r = copy_out(c, boxes_out, c->d_boxes, need * sizeof(yolo_box), out_loc); if (r) return r; }
+    if (counts_out) { int r = copy_out(c, counts_out, c->d_counts, (size_t)n * 4, out_loc); if (r) return r; }
+    return YOLO_OK;
+}
+
+// a throw-away context for the single-operator entry points
+struct OpScope {
+    hipStream_t s = nullptr; std::vector<void *> bufs; int rc = YOLO_OK; std::string err;
+    explicit OpScope(int device) { if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&s) != hipSuccess) rc = YOLO_ERR_HIP; }
+    ~OpScope() { for (void *p : bufs) hipFree(p); if (s) hipStreamDestroy(s); }
+    void *alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes + 256) != hipSuccess) { rc = YOLO_ERR_NOMEM; return nullptr; } hipMemsetAsync(p, 0, bytes + 256, s); bufs.push_back(p); return p; }
+    void *upload(const void *h, size_t bytes) { void *p = alloc(bytes); if (p && hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, s) != hipSuccess) rc = YOLO_ERR_HIP; return p; }
+    int download(void *h, const void *d, size_t bytes) { if (hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = YOLO_ERR_HIP; return rc; }
+    bool ok(hipError_t e) { if (e != hipSuccess) { rc = YOLO_ERR_HIP; err = hipGetErrorString(e); } return e == hipSuccess; }
+};
+thread_local std::string g_op_err;
+
+TView make_view(void *p, int n, int h, int w, int c, int stride, int f32) { TView v; v.ptr = p; v.n = n; v.h = h; v.w = w; v.c = c; v.stride = stride; v.f32 = f32; return v; }
+
+// fold + pack one conv's parameters (host).  w_oihw: [cout][cin][k][k]
+void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, bool f32, std::vector<uint8_t> &wbuf, std::vector<float> &bias)
+{
+    const int n = L.filters, k = L.size, cin = L.cin;
+    bias.assign(L.cout_pad, 0.f);
+    std::vector<float> scale(n, 1.f);
+    if (L.bn) {
+        const float *beta = bn_or_bias, *gamma = beta + n, *mean = gamma + n, *var = mean + n;
+        for (int o = 0; o < n; ++o) {
+            float s = gamma[o] / sqrtf(var[o] + 1e-5f);           // TF epsilon inside the sqrt (V3/yolo_v3.py:9)
+            scale[o] = s; bias[o] = beta[o] - mean[o] * s;
+        }
+    } else {
+        for (int o = 0; o < n; ++o) bias[o] = bn_or_bias[o];
+    }
+    const size_t es = f32 ? 4 : 2;
+    wbuf.assign((size_t)L.cout_pad * L.kpad * es, 0);
+    for (int o = 0; o < n; ++o)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int kh = 0; kh < k; ++kh)
+                for (int kw = 0; kw < k; ++kw) {
+                    float v = w_oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] * scale[o];
+                    size_t idx = (size_t)o * L.kpad + (size_t)(kh * k + kw) * L.cin_pad + ci;
+                    if (f32) memcpy(&wbuf[idx * 4], &v, 4);
+                    else { uint16_t b = f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
+                }
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
+{
+    auto bail = [&](yolo_ctx *c, const std::string &m) -> yolo_ctx * { if (err && err_len) snprintf(err, err_len, "%s", m.c_str()); if (c) yolo_destroy(c); return nullptr; };
+    if (!cfg || cfg->struct_size != sizeof(yolo_config)) return bail(nullptr, "yolo_create: bad yolo_config (struct_size)");
+    if (cfg->max_batch < 1) return bail(nullptr, "yolo_create: max_batch < 1");
+    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32) return bail(nullptr, "yolo_create: dtype");
+    yolo_ctx *c = new yolo_ctx();
+    c->device = cfg->device; c->max_batch = cfg->max_batch; c->dtype = cfg->dtype; c->semantics = cfg->semantics;
+    c->decode = cfg->decode; c->keep_layers = cfg->keep_layers;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bail(c, "yolo_create: no HIP device (this library has no CPU fallback)");
+    if (hipSetDevice(c->device) != hipSuccess) return bail(c, "yolo_create: hipSetDevice failed");
+    if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    else { if (hipStreamCreate(&c->stream) != hipSuccess) return bail(c, "yolo_create: hipStreamCreate failed"); c->own_stream = true; }
+    std::vector<Section> secs; std::string perr;
+    if (!parse_cfg(cfg->cfg_text, secs, perr)) return bail(c, perr);
+    if (build_plan(c, secs) != YOLO_OK) return bail(c, c->err);
+    if (allocate(c) != YOLO_OK) return bail(c, c->err);
+    return c;
+}
+
+void yolo_destroy(yolo_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->phys) if (p) hipFree(p);
+    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); }
+    void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *yolo_last_error(const yolo_ctx *c) { return c ? c->err.c_str() : g_op_err.c_str(); }
+
+size_t yolo_weights_count(const yolo_ctx *c) { return c ? c->weights_count : 0; }
+
+int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!flat) return fail(c, YOLO_ERR_INVALID, "weights == NULL");
+    if (n != c->weights_count) return fail(c, YOLO_ERR_IO, "weights stream has %zu floats, topology needs %zu", n, c->weights_count);
+    HIPCK(c, hipSetDevice(c->device));
+    const float *p = flat;
+    std::vector<uint8_t> wbuf; std::vector<float> bias;
+    for (auto &L : c->layers) {
+        if (L.type != L_CONV) continue;
+        const float *params = p; p += (size_t)L.filters * (L.bn ? 4 : 1);
+        const float *w = p; p += (size_t)L.filters * L.cin * L.size * L.size;
+        pack_conv(L, params, w, c->elem_f32(), wbuf, bias);
+        HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
+        HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->weights_loaded = true;
+    return YOLO_OK;
+}
+
+int yolo_load_darknet_weights(yolo_ctx *c, const char *path, int header_ints)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return fail(c, YOLO_ERR_IO, "cannot open weights file '%s'", path ? path : "(null)");
+    int32_t ver[3];
+    if (fread(ver, 4, 3, f) != 3) { fclose(f); return fail(c, YOLO_ERR_IO, "truncated header in '%s'", path); }
+    if (header_ints == 0) header_ints = (ver[0] * 10 + ver[1]) >= 2 ? 5 : 4;      // DN/parser.c:1259-1265
+    if (header_ints != 4 && header_ints != 5) { fclose(f); return fail(c, YOLO_ERR_INVALID, "header_ints must be 0, 4 or 5"); }
+    fseek(f, 0, SEEK_END); long end = ftell(f); fseek(f, header_ints * 4, SEEK_SET);
+    size_t n = (size_t)(end - header_ints * 4) / 4;
+    if (n != c->weights_count) { fclose(f); return fail(c, YOLO_ERR_IO, "'%s' holds %zu floats after a %d-int header, topology needs %zu", path, n, header_ints, c->weights_count); }
+    std::vector<float> flat(n);
+    size_t got = fread(flat.data(), 4, n, f); fclose(f);
+    if (got != n) return fail(c, YOLO_ERR_IO, "short read on '%s'", path);
+    return yolo_set_weights(c, flat.data(), n);
+}
+
+int yolo_input_size(const yolo_ctx *c, int *h, int *w, int *ch) { if (!c) return YOLO_ERR_INVALID; if (h) *h = c->in_h; if (w) *w = c->in_w; if (ch) *ch = c->in_c; return YOLO_OK; }
+int yolo_num_rows(const yolo_ctx *c) { return c ? c->rows : YOLO_ERR_INVALID; }
+int yolo_num_attrs(const yolo_ctx *c) { return c ? c->attrs : YOLO_ERR_INVALID; }
+int yolo_num_layers(const yolo_ctx *c) { return c ? (int)c->layers.size() : YOLO_ERR_INVALID; }
+double yolo_conv_flops(const yolo_ctx *c) { return c ? c->conv_flops : 0; }
+double yolo_conv_bytes(const yolo_ctx *c, int n)
+{
+    if (!c) return 0;
+    double b = 0;
+    for (auto &L : c->layers) if (L.type == L_CONV) {
+        TView in = view_of(c, L.in[0]);
+        b += (double)n * in.h * in.w * L.cin * 2.0 + (double)n * L.H * L.W * L.filters * 2.0 + (double)L.filters * L.cin * L.size * L.size * 2.0;
+    }
+    return b;
+}
+
+int yolo_forward(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward before weights were loaded");
+    if (fmt != YOLO_IMG_U8 && fmt != YOLO_IMG_F32) return fail(c, YOLO_ERR_INVALID, "bad image format");
+    HIPCK(c, hipSetDevice(c->device));
+    int r = stage_in(c, images, n, fmt, loc, scale); if (r) return r;
+    r = run_network(c, n); if (r) return r;
+    if (det_out) return copy_out(c, det_out, c->d_det, (size_t)n * c->rows * c->attrs * 4, out_loc);
+    return YOLO_OK;
+}
+
+int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int loc, float *det_out, int out_loc)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward_image_u8 before weights were loaded");
+    if (!image || h < 1 || w < 1) return fail(c, YOLO_ERR_INVALID, "bad image");
+    HIPCK(c, hipSetDevice(c->device));
+    const uint8_t *src = image; void *tmp = nullptr;
+    if (loc == YOLO_HOST) {
+        HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3));
+        HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
+    }
+    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.f32, 8, 8, c->stream);
+    int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
+    if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
+    if (r) return r;
+    if (det_out) return copy_out(c, det_out, c->d_det, (size_t)c->rows * c->attrs * 4, out_loc);
+    return YOLO_OK;
+}
+
+int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
+                     yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "postprocess of %d images but the last forward ran %d", n, c->last_n);
+    HIPCK(c, hipSetDevice(c->device));
+    return post(c, c->d_det, n, c->rows, c->attrs, score_thr, iou_thr, max_out, nms_mode, select_mode,
+                nms_mode == YOLO_NMS_PER_CLASS ? c->in_h : 0, nms_mode == YOLO_NMS_PER_CLASS ? c->in_w : 0, boxes_out, counts_out, out_loc);
+}
+
+int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float score_thr, float iou_thr,
+                int max_out, int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+{
+    int r = yolo_forward(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE); if (r) return r;
+    return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, out_loc);
+}
+
+int yolo_synchronize(yolo_ctx *c) { if (!c) return YOLO_ERR_INVALID; HIPCK(c, hipStreamSynchronize(c->stream)); return YOLO_OK; }
+
+int yolo_layer_output(yolo_ctx *c, int index, int n, float *out, size_t out_floats, int *dims_out)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->keep_layers) return fail(c, YOLO_ERR_STATE, "yolo_layer_output needs keep_layers=1");
+    if (index < 0 || index >= (int)c->layers.size() || n < 1 || n > c->last_n) return fail(c, YOLO_ERR_INVALID, "bad layer index / n");
+    const Layer &L = c->layers[index];
+    if (dims_out) { dims_out[0] = L.H; dims_out[1] = L.W; dims_out[2] = L.C; }
+    size_t need = (size_t)n * L.H * L.W * L.C;
+    if (!out) return YOLO_OK;
+    if (out_floats < need) return fail(c, YOLO_ERR_INVALID, "output buffer too small");
+    HIPCK(c, hipSetDevice(c->device));
+    float *tmp = nullptr; HIPCK(c, hipMalloc((void **)&tmp, need * 4));
+    TView v = L.out; v.n = n;
+    hipError_t e = launch_to_f32(v, tmp, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, need * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(c, YOLO_ERR_HIP, "layer_output: %s", hipGetErrorString(e));
+    return YOLO_OK;
+}
+
+int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *conv_ms)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "weights not loaded");
+    if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
+    HIPCK(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1; HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    if (total_ms) {
+        HIPCK(c, hipEventRecord(e0, c->stream));
+        for (int it = 0; it < iters; ++it) { int r = run_network(c, n); if (r) return r; }
+        HIPCK(c, hipEventRecord(e1, c->stream)); HIPCK(c, hipEventSynchronize(e1));
+        float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); *total_ms = ms / iters;
+    }
+    if (conv_ms) {
+        int nconv = 0; for (auto &L : c->layers) nconv += L.type == L_CONV;
+        std::vector<hipEvent_t> ev(2 * (size_t)nconv);
+        for (auto &e : ev) HIPCK(c, hipEventCreate(&e));
+        double acc = 0;
+        for (int it = 0; it < iters; ++it) {
+            int k = 0;
+            for (int i = 0; i < (int)c->layers.size(); ++i) {
+                bool cv = c->layers[i].type == L_CONV;
+                if (cv) HIPCK(c, hipEventRecord(ev[2 * k], c->stream));
+                int r = run_layer(c, i, n); if (r) return r;
+                if (cv) { HIPCK(c, hipEventRecord(ev[2 * k + 1], c->stream)); ++k; }
+            }
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            for (int j = 0; j < nconv; ++j) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1])); acc += ms; }
+        }
+        for (auto &e : ev) hipEventDestroy(e);
+        *conv_ms = (float)(acc / iters);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return YOLO_OK;
+}
+
+int yolo_time_layers(yolo_ctx *c, int n, int iters, float *ms_out)
+{
+    if (!c || !ms_out) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "weights not loaded");
+    if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
+    HIPCK(c, hipSetDevice(c->device));
+    const int NL = (int)c->layers.size();
+    std::vector<hipEvent_t> ev(NL + 1);
+    for (auto &e : ev) HIPCK(c, hipEventCreate(&e));
+    std::vector<double> acc(NL, 0.0);
+    for (int it = 0; it < iters; ++it) {
+        HIPCK(c, hipEventRecord(ev[0], c->stream));
+        for (int i = 0; i < NL; ++i) { int r = run_layer(c, i, n); if (r) return r; HIPCK(c, hipEventRecord(ev[i + 1], c->stream)); }
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < NL; ++i) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
+    }
+    for (int i = 0; i < NL; ++i) ms_out[i] = (float)(acc[i] / iters);
+    for (auto &e : ev) hipEventDestroy(e);
+    c->last_n = n;
+    return YOLO_OK;
+}
+
+int yolo_autotune(yolo_ctx *c, int n, int iters)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "weights not loaded");
+    if (c->dtype != YOLO_BF16) return YOLO_OK;
+    if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
+    HIPCK(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1; HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    std::map<std::string, int> memo;
+    for (auto &L : c->layers) {
+        if (L.type != L_CONV) continue;
+        ConvArgs a = conv_args(c, L, n);
+        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.out_f32, a.res != nullptr);
+        auto it = memo.find(key);
+        if (it != memo.end()) { L.tile_cfg = it->second; continue; }
+        float best = 1e30f; int best_cfg = conv_pick_cfg(a);
+        for (int cfg = 0; cfg < conv_num_cfgs(); ++cfg) {
+            if (launch_conv_bf16(a, cfg, c->stream) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm-up
+            HIPCK(c, hipEventRecord(e0, c->stream));
+            for (int r = 0; r < iters; ++r) launch_conv_bf16(a, cfg, c->stream);
+            HIPCK(c, hipEventRecord(e1, c->stream)); HIPCK(c, hipEventSynchronize(e1));
+            float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) { best = ms; best_cfg = cfg; }
+        }
+        L.tile_cfg = best_cfg; memo[key] = best_cfg;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return YOLO_OK;
+}
+
+// ---- single operators -----------------------------------------------------------------------
+int yolo_op_conv_num_cfgs(void) { return conv_num_cfgs(); }
+
+int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_hwio, const float *bias, int k, int stride,
+                   int cout, int act, const float *residual, float *out, int dtype, int tile_cfg, int device)
+{
+    if (!x || !w_hwio || !out || n < 1 || (k != 1 && k != 3) || stride < 1) { g_op_err = "conv2d: bad arguments"; return YOLO_ERR_INVALID; }
+    OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
+    const bool f32 = dtype == YOLO_FP32; const size_t es = f32 ? 4 : 2;
+    Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act;
+    L.cin = cin; L.cin_pad = roundup(cin, 8); L.kpad = roundup(k * k * L.cin_pad, 64); L.cout_pad = roundup(cout, 256);
+    const int ho = (h + 2 * L.pad - k) / stride + 1, wo = (w + 2 * L.pad - k) / stride + 1;
+    // HWIO -> OIHW for the common packer
+    std::vector<float> oihw((size_t)cout * cin * k * k), b0(cout, 0.f);
+    for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int ci = 0; ci < cin; ++ci) for (int o = 0; o < cout; ++o)
+        oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] = w_hwio[(((size_t)kh * k + kw) * cin + ci) * cout + o];
+    if (bias) memcpy(b0.data(), bias, (size_t)cout * 4);
+    std::vector<uint8_t> wbuf; std::vector<float> bv; pack_conv(L, b0.data(), oihw.data(), f32, wbuf, bv);
+    void *d_w = S.upload(wbuf.data(), wbuf.size()); float *d_b = (float *)S.upload(bv.data(), bv.size() * 4);
+    float *d_x32 = (float *)S.upload(x, (size_t)n * h * w * cin * 4);
+    void *d_x = S.alloc((size_t)n * h * w * L.cin_pad * es);
+    const int cstride = roundup(cout, 8);
+    void *d_o = S.alloc((size_t)n * ho * wo * cstride * es); float *d_o32 = (float *)S.alloc((size_t)n * ho * wo * cout * 4);
+    void *d_r = nullptr;
+    void *d_z = S.alloc(4096);
+    if (S.rc) { g_op_err = "conv2d: allocation failed"; return S.rc; }
+    TView vx = make_view(d_x, n, h, w, cin, L.cin_pad, f32);
+    if (!S.ok(launch_from_f32(d_x32, vx, S.s))) { g_op_err = S.err; return S.rc; }
+    if (residual) {
+        float *d_r32 = (float *)S.upload(residual, (size_t)n * ho * wo * cout * 4); d_r = S.alloc((size_t)n * ho * wo * cstride * es);
+        if (S.rc) return S.rc;
+        if (!S.ok(launch_from_f32(d_r32, make_view(d_r, n, ho, wo, cout, cstride, f32), S.s))) { g_op_err = S.err; return S.rc; }
+    }
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = d_x; a.in_stride = L.cin_pad; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = cstride; a.out_f32 = f32;
+    a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
+    a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = act; a.zeros = d_z;
+    hipError_t e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
+    if (!S.ok(e)) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
+    if (!S.ok(launch_to_f32(make_view(d_o, n, ho, wo, cout, cstride, f32), d_o32, S.s))) { g_op_err = S.err; return S.rc; }
+    S.download(out, d_o32, (size_t)n * ho * wo * cout * 4);
+    if (S.rc) g_op_err = "conv2d: " + std::string(hipGetErrorString(hipGetLastError()));
+    return S.rc;
+}
+
+static int ew_op(int kind, const float *x, int n, int h, int w, int c, int p0, int p1, int p2, float *out, int device)
+{
+    if (!x || !out || c % 8) { g_op_err = "op: bad arguments (channels must be a multiple of 8)"; return YOLO_ERR_INVALID; }
+    OpScope S(device); if (S.rc) { g_op_err = "op: no HIP device"; return S.rc; }
+    int ho = h, wo = w, co = c;
+    if (kind == 0) { ho = 2 * h; wo = 2 * w; }
+    else if (kind == 1) { ho = h / p0; wo = w / p0; co = c * p0 * p0; }
+    else { int pad = (p0 - 1) / 2; ho = (h + 2 * pad) / p1; wo = (w + 2 * pad) / p1; }
+    float *d_x32 = (float *)S.upload(x, (size_t)n * h * w * c * 4);
+    void *d_x = S.alloc((size_t)n * h * w * c * 2), *d_o = S.alloc((size_t)n * ho * wo * co * 2);
+    float *d_o32 = (float *)S.alloc((size_t)n * ho * wo * co * 4);
+    if (S.rc) return S.rc;
+    TView vi = make_view(d_x, n, h, w, c, c, 0), vo = make_view(d_o, n, ho, wo, co, co, 0);
+    bool ok = S.ok(launch_from_f32(d_x32, vi, S.s));
+    if (ok && kind == 0) ok = S.ok(launch_upsample2x(vi, vo, p0 == YOLO_SEM_TF, S.s));
+    if (ok && kind == 1) ok = S.ok(launch_reorg(vi, vo, p0, p1 == YOLO_SEM_DARKNET, S.s));
+    if (ok && kind == 2) ok = S.ok(launch_maxpool(vi, vo, p0, p1, (p0 - 1) / 2, S.s));
+    if (ok) ok = S.ok(launch_to_f32(vo, d_o32, S.s));
+    if (!ok) { g_op_err = S.err; return S.rc; }
+    return S.download(out, d_o32, (size_t)n * ho * wo * co * 4);
+}
+int yolo_op_upsample2x(const float *x, int n, int h, int w, int c, int semantics, float *out, int device) { return ew_op(0, x, n, h, w, c, semantics, 0, 0, out, device); }
+int yolo_op_reorg(const float *x, int n, int h, int w, int c, int stride, int semantics, float *out, int device) { return ew_op(1, x, n, h, w, c, stride, semantics, 0, out, device); }
+int yolo_op_maxpool(const float *x, int n, int h, int w, int c, int size, int stride, float *out, int device) { return ew_op(2, x, n, h, w, c, size, stride, 0, out, device); }
+
+int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float *out, int device)
+{
+    if (!img || !out || h < 1 || w < 1 || s < 1) return YOLO_ERR_INVALID;
+    OpScope S(device); if (S.rc) return S.rc;
+    uint8_t *d_i = (uint8_t *)S.upload(img, (size_t)h * w * 3); float *d_o = (float *)S.alloc((size_t)s * s * 3 * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_resize_u8(d_i, h, w, s, d_o, 1, 3, 3, S.s))) { g_op_err = S.err; return S.rc; }
+    return S.download(out, d_o, (size_t)s * s * 3 * 4);
+}
+
+int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const float *anchors_wh, int img_size, int decode,
+                   int region, float *out, int device)
+{
+    if (!raw || !out || !anchors_wh || na < 1 || na > 16) return YOLO_ERR_INVALID;
+    OpScope S(device); if (S.rc) return S.rc;
+    const int attrs = 5 + classes; const size_t cnt = (size_t)n * g * g * na * attrs;
+    float *d_r = (float *)S.upload(raw, cnt * 4), *d_o = (float *)S.alloc(cnt * 4);
+    if (S.rc) return S.rc;
+    DecodeArgs d; memset(&d, 0, sizeof d);
+    d.raw = d_r; d.raw_stride = na * attrs; d.n = n; d.g = g; d.na = na; d.classes = classes; d.img_size = img_size; d.mode = decode; d.region = region;
+    const int stride = img_size / g;
+    for (int k = 0; k < 2 * na; ++k) d.anchors[k] = region ? anchors_wh[k] : (float)(1.0 * (double)anchors_wh[k] / (double)stride);
+    d.det = d_o; d.rows_total = g * g * na; d.row_off = 0;
+    if (!S.ok(launch_decode(d, S.s))) { g_op_err = S.err; return S.rc; }
+    return S.download(out, d_o, cnt * 4);
+}
+
+int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out, int nms_mode,
+                        int select_mode, yolo_box *boxes_out, int32_t *counts_out, int device)
+{
+    if (!det || !boxes_out || !counts_out || n < 1 || rows < 1 || rows > 32768 || attrs < 6 || max_out < 1) return YOLO_ERR_INVALID;
+    OpScope S(device); if (S.rc) return S.rc;
+    size_t nr = (size_t)n * rows; int p2 = 1; while (p2 < rows) p2 <<= 1;
+    PostArgs p; memset(&p, 0, sizeof p);
+    p.det = (const float *)S.upload(det, nr * attrs * 4); p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr;
+    p.max_out = max_out; p.nms_mode = nms_mode & 0xff; p.select_mode = select_mode;
+    // bits 8.. of nms_mode carry the image size for the V2 numpy flavour: (h << 8) | (w << 20)
+    p.img_h = (nms_mode >> 8) & 0xfff; p.img_w = (nms_mode >> 20) & 0xfff;
+    p.scores = (float *)S.alloc(nr * 4); p.labels = (int *)S.alloc(nr * 4); p.cand = (int *)S.alloc(nr * 4);
+    p.keys = (unsigned long long *)S.alloc((size_t)n * p2 * 8); p.rows_pow2 = p2;
+    p.sbox = (float4 *)S.alloc(nr * 16); p.slabel = (int *)S.alloc(nr * 4); p.sscore = (float *)S.alloc(nr * 4);
+    p.boxes_out = S.alloc((size_t)n * max_out * sizeof(yolo_box)); p.counts_out = (int *)S.alloc((size_t)n * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_postprocess(p, S.s))) { g_op_err = S.err; return S.rc; }
+    S.download(boxes_out, p.boxes_out, (size_t)n * max_out * sizeof(yolo_box));
+    return S.download(counts_out, p.counts_out, (size_t)n * 4);
+}
+
+}  // extern "C"

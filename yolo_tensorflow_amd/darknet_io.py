@@ -147,7 +147,8 @@ def synth_weights(secs, seed=0, obj_bias=-4.0):
                     b[:, 4] = obj_bias + rng.normal(0, .5, na)
                     b = b.reshape(-1)
             parts.append(b)
-            parts.append(rng.normal(0, np.sqrt(1.0 / (k * k * cin)), n * cin * k * k))
+            # head pre-activations stay O(1) so exp(tw) cannot overflow on synthetic inputs
+            parts.append(rng.normal(0, 0.25 * np.sqrt(1.0 / (k * k * cin)), n * cin * k * k))
     return np.concatenate(parts).astype(np.float32)
 
 

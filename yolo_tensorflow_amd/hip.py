@@ -1,0 +1,307 @@
+"""ctypes shim over libyolo_hip.so (the C ABI in include/yolo_hip.h).
+
+This is the only module that talks to the device.  It replaces the reference's `tf.Session.run`
+boundary (V3/YOLO_V3_inference.py:106-107) and plays the role D2T/darknet.py:48-115 plays for
+libdarknet.so.  There is deliberately **no CPU fallback**: if the library is missing or no HIP
+device is visible every entry point raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+
+BF16, FP32 = 0, 1
+SEM_TF, SEM_DARKNET = 0, 1
+DECODE_RATIO, DECODE_PIXEL = 0, 1
+HOST, DEVICE = 0, 1
+IMG_U8, IMG_F32 = 0, 1
+NMS_TF, NMS_PER_CLASS, NMS_DARKNET = 0, 1, 2
+SELECT_GT, SELECT_GE = 0, 1
+
+BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("score", "<f4"), ("cls", "<i4")])
+
+EXPORTS = [
+    "yolo_create", "yolo_destroy", "yolo_last_error", "yolo_load_darknet_weights", "yolo_set_weights",
+    "yolo_weights_count", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
+    "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
+    "yolo_detect", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
+    "yolo_autotune", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
+    "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_decode", "yolo_op_postprocess",
+]
+
+
+class YoloError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("cfg_text", C.c_char_p), ("max_batch", C.c_int32),
+                ("dtype", C.c_int32), ("semantics", C.c_int32), ("decode", C.c_int32), ("device", C.c_int32),
+                ("keep_layers", C.c_int32), ("stream", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libyolo_hip.so and declare every prototype; raises YoloError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloError("%s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C yolo_tensorflow_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    l = C.CDLL(LIB_PATH)
+    P, I, F, D = C.c_void_p, C.c_int, C.c_float, C.c_double
+    FP = C.POINTER(C.c_float)
+    l.yolo_create.argtypes = [C.POINTER(_Config), C.c_char_p, C.c_size_t]; l.yolo_create.restype = P
+    l.yolo_destroy.argtypes = [P]; l.yolo_destroy.restype = None
+    l.yolo_last_error.argtypes = [P]; l.yolo_last_error.restype = C.c_char_p
+    l.yolo_load_darknet_weights.argtypes = [P, C.c_char_p, I]
+    l.yolo_set_weights.argtypes = [P, FP, C.c_size_t]
+    l.yolo_weights_count.argtypes = [P]; l.yolo_weights_count.restype = C.c_size_t
+    l.yolo_input_size.argtypes = [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]
+    for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_synchronize"):
+        getattr(l, n).argtypes = [P]
+    l.yolo_conv_flops.argtypes = [P]; l.yolo_conv_flops.restype = D
+    l.yolo_conv_bytes.argtypes = [P, I]; l.yolo_conv_bytes.restype = D
+    l.yolo_forward.argtypes = [P, P, I, I, I, F, P, I]
+    l.yolo_forward_image_u8.argtypes = [P, P, I, I, I, P, I]
+    l.yolo_postprocess.argtypes = [P, I, F, F, I, I, I, P, P, I]
+    l.yolo_detect.argtypes = [P, P, I, I, I, F, F, F, I, I, I, P, P, I]
+    l.yolo_layer_output.argtypes = [P, I, I, P, C.c_size_t, C.POINTER(I)]
+    l.yolo_time_forward.argtypes = [P, I, I, FP, FP]
+    l.yolo_time_layers.argtypes = [P, I, I, FP]
+    l.yolo_autotune.argtypes = [P, I, I]
+    l.yolo_op_conv2d.argtypes = [P, I, I, I, I, P, P, I, I, I, I, P, P, I, I, I]
+    l.yolo_op_conv_num_cfgs.argtypes = []
+    l.yolo_op_upsample2x.argtypes = [P, I, I, I, I, I, P, I]
+    l.yolo_op_reorg.argtypes = [P, I, I, I, I, I, I, P, I]
+    l.yolo_op_maxpool.argtypes = [P, I, I, I, I, I, I, P, I]
+    l.yolo_op_resize_u8.argtypes = [P, I, I, I, P, I]
+    l.yolo_op_decode.argtypes = [P, I, I, I, I, P, I, I, I, P, I]
+    l.yolo_op_postprocess.argtypes = [P, I, I, I, F, F, I, I, I, P, P, I]
+    _lib = l
+    return l
+
+
+def _ptr(a):
+    """host numpy array / torch tensor (host or device) / raw int pointer -> (void*, location)."""
+    if a is None:
+        return None, HOST
+    if isinstance(a, int):
+        return C.c_void_p(a), DEVICE
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise YoloError("array must be C-contiguous")
+        return C.c_void_p(a.ctypes.data), HOST
+    if hasattr(a, "data_ptr"):   # torch tensor, no torch import needed
+        if not a.is_contiguous():
+            raise YoloError("tensor must be contiguous")
+        return C.c_void_p(a.data_ptr()), (DEVICE if a.is_cuda else HOST)
+    raise YoloError("unsupported buffer type %r" % type(a))
+
+
+def _op_check(rc, what):
+    if rc != 0:
+        msg = load_library().yolo_last_error(None)
+        raise YoloError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+class Engine:
+    """One planned network on one GPU (a `yolo_ctx`)."""
+
+    def __init__(self, cfg_text, max_batch=1, dtype=BF16, semantics=SEM_TF, decode=DECODE_RATIO, device=0,
+                 keep_layers=False, stream=None):
+        self.lib = load_library()
+        self._cfg_bytes = cfg_text.encode()
+        conf = _Config(C.sizeof(_Config), self._cfg_bytes, max_batch, dtype, semantics, decode, device,
+                       1 if keep_layers else 0, C.c_void_p(stream) if stream else None)
+        err = C.create_string_buffer(512)
+        self.ctx = self.lib.yolo_create(C.byref(conf), err, 512)
+        if not self.ctx:
+            raise YoloError("yolo_create: " + err.value.decode())
+        h, w, ch = C.c_int(), C.c_int(), C.c_int()
+        self.lib.yolo_input_size(self.ctx, C.byref(h), C.byref(w), C.byref(ch))
+        self.size = h.value
+        self.rows = self.lib.yolo_num_rows(self.ctx)
+        self.attrs = self.lib.yolo_num_attrs(self.ctx)
+        self.num_layers = self.lib.yolo_num_layers(self.ctx)
+        self.max_batch = max_batch
+        self.dtype = dtype
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise YoloError("%s failed (%d): %s" % (what, rc, self.lib.yolo_last_error(self.ctx).decode()))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.yolo_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def weights_count(self):
+        return self.lib.yolo_weights_count(self.ctx)
+
+    def load_weights(self, path, header_ints=0):
+        self._check(self.lib.yolo_load_darknet_weights(self.ctx, os.fsencode(path), header_ints), "yolo_load_darknet_weights")
+
+    def set_weights(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        self._check(self.lib.yolo_set_weights(self.ctx, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size), "yolo_set_weights")
+
+    # ---- hot path ----
+    def forward(self, images, scale=1.0 / 255.0, want_detections=True, n=None, fmt=None, out=None):
+        """images: uint8 or float32 [n,S,S,3] (numpy, torch host/device tensor, or raw device pointer with
+        n and fmt given).  Returns the decoded tensor [n, rows, attrs] (numpy) unless out/want_detections say otherwise."""
+        p, loc = _ptr(images)
+        if n is None:
+            n = int(images.shape[0])
+        if fmt is None:
+            fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
+        det = None
+        dp, dloc = None, HOST
+        if out is not None:
+            dp, dloc = _ptr(out)
+        elif want_detections:
+            det = np.empty((n, self.rows, self.attrs), dtype=np.float32)
+            dp, dloc = _ptr(det)
+        self._check(self.lib.yolo_forward(self.ctx, p, n, fmt, loc, scale, dp, dloc), "yolo_forward")
+        return det
+
+    def forward_image(self, image_u8):
+        """One uint8 RGB image of any size: /255 + legacy bilinear stretch on the device, then forward."""
+        image_u8 = np.ascontiguousarray(image_u8, dtype=np.uint8)
+        det = np.empty((1, self.rows, self.attrs), dtype=np.float32)
+        self._check(self.lib.yolo_forward_image_u8(self.ctx, image_u8.ctypes.data, image_u8.shape[0], image_u8.shape[1],
+                                                   HOST, det.ctypes.data, HOST), "yolo_forward_image_u8")
+        return det
+
+    def postprocess(self, n, score_thr=0.5, iou_thr=0.5, max_out=20, nms_mode=NMS_TF, select_mode=SELECT_GT,
+                    boxes_out=None, counts_out=None):
+        """-> list of structured arrays (BOX_DTYPE) per image, or writes into the given device buffers."""
+        if boxes_out is not None:
+            bp, bloc = _ptr(boxes_out); cp, _ = _ptr(counts_out)
+            self._check(self.lib.yolo_postprocess(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode, bp, cp, bloc), "yolo_postprocess")
+            return None
+        boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.yolo_postprocess(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode,
+                                              boxes.ctypes.data, counts.ctypes.data, HOST), "yolo_postprocess")
+        return [boxes[i, :counts[i]].copy() for i in range(n)]
+
+    def detect(self, images, scale=1.0 / 255.0, **kw):
+        self.forward(images, scale=scale, want_detections=False)
+        return self.postprocess(int(images.shape[0]), **kw)
+
+    def synchronize(self):
+        self._check(self.lib.yolo_synchronize(self.ctx), "yolo_synchronize")
+
+    # ---- introspection / measurement ----
+    def layer_output(self, index, n):
+        dims = (C.c_int * 3)()
+        self._check(self.lib.yolo_layer_output(self.ctx, index, n, None, 0, dims), "yolo_layer_output")
+        out = np.empty((n, dims[0], dims[1], dims[2]), dtype=np.float32)
+        self._check(self.lib.yolo_layer_output(self.ctx, index, n, out.ctypes.data, out.size, dims), "yolo_layer_output")
+        return out
+
+    def conv_flops(self):
+        return self.lib.yolo_conv_flops(self.ctx)
+
+    def conv_bytes(self, n):
+        return self.lib.yolo_conv_bytes(self.ctx, n)
+
+    def time_forward(self, n, iters, conv=True):
+        t, c = C.c_float(0), C.c_float(0)
+        self._check(self.lib.yolo_time_forward(self.ctx, n, iters, C.byref(t), C.byref(c) if conv else None), "yolo_time_forward")
+        return t.value, (c.value if conv else None)
+
+    def time_layers(self, n, iters):
+        ms = np.zeros(self.num_layers, dtype=np.float32)
+        self._check(self.lib.yolo_time_layers(self.ctx, n, iters, ms.ctypes.data_as(C.POINTER(C.c_float))), "yolo_time_layers")
+        return ms
+
+    def autotune(self, n, iters=3):
+        self._check(self.lib.yolo_autotune(self.ctx, n, iters), "yolo_autotune")
+
+
+# ---- single operators (host buffers in, host buffers out; production kernels underneath) ----------
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def op_conv2d(x, w_hwio, bias=None, stride=1, act=0, residual=None, dtype=BF16, tile_cfg=-1, device=0):
+    l = load_library()
+    x = _f32(x); w = _f32(w_hwio)
+    n, h, wd, cin = x.shape
+    k, _, _, cout = w.shape
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    out = np.empty((n, ho, wo, cout), dtype=np.float32)
+    b = _f32(bias) if bias is not None else None
+    r = _f32(residual) if residual is not None else None
+    rc = l.yolo_op_conv2d(x.ctypes.data, n, h, wd, cin, w.ctypes.data, b.ctypes.data if b is not None else None, k, stride,
+                          cout, act, r.ctypes.data if r is not None else None, out.ctypes.data, dtype, tile_cfg, device)
+    _op_check(rc, "yolo_op_conv2d")
+    return out
+
+
+def op_conv_num_cfgs():
+    return load_library().yolo_op_conv_num_cfgs()
+
+
+def op_upsample2x(x, semantics=SEM_TF, device=0):
+    x = _f32(x); n, h, w, c = x.shape
+    out = np.empty((n, 2 * h, 2 * w, c), dtype=np.float32)
+    _op_check(load_library().yolo_op_upsample2x(x.ctypes.data, n, h, w, c, semantics, out.ctypes.data, device), "yolo_op_upsample2x")
+    return out
+
+
+def op_reorg(x, stride=2, semantics=SEM_TF, device=0):
+    x = _f32(x); n, h, w, c = x.shape
+    out = np.empty((n, h // stride, w // stride, c * stride * stride), dtype=np.float32)
+    _op_check(load_library().yolo_op_reorg(x.ctypes.data, n, h, w, c, stride, semantics, out.ctypes.data, device), "yolo_op_reorg")
+    return out
+
+
+def op_maxpool(x, size=2, stride=2, device=0):
+    x = _f32(x); n, h, w, c = x.shape
+    pad = (size - 1) // 2
+    out = np.empty((n, (h + 2 * pad) // stride, (w + 2 * pad) // stride, c), dtype=np.float32)
+    _op_check(load_library().yolo_op_maxpool(x.ctypes.data, n, h, w, c, size, stride, out.ctypes.data, device), "yolo_op_maxpool")
+    return out
+
+
+def op_resize_u8(img, size, device=0):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((size, size, 3), dtype=np.float32)
+    _op_check(load_library().yolo_op_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], size, out.ctypes.data, device), "yolo_op_resize_u8")
+    return out
+
+
+def op_decode(raw, anchors, classes, img_size, decode=DECODE_RATIO, region=False, device=0):
+    raw = _f32(raw); n, g = raw.shape[0], raw.shape[1]
+    anchors = _f32(anchors).reshape(-1)
+    na = anchors.size // 2
+    out = np.empty((n, g * g * na, 5 + classes), dtype=np.float32)
+    _op_check(load_library().yolo_op_decode(raw.ctypes.data, n, g, na, classes, anchors.ctypes.data, img_size, decode,
+                                            1 if region else 0, out.ctypes.data, device), "yolo_op_decode")
+    return out
+
+
+def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mode=SELECT_GT, image_hw=None, device=0):
+    det = _f32(det); n, rows, attrs = det.shape
+    mode = nms_mode
+    if image_hw is not None:
+        mode |= (int(image_hw[0]) << 8) | (int(image_hw[1]) << 20)
+    boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)
+    _op_check(load_library().yolo_op_postprocess(det.ctypes.data, n, rows, attrs, score_thr, iou_thr, max_out, mode, select_mode,
+                                                 boxes.ctypes.data, counts.ctypes.data, device), "yolo_op_postprocess")
+    return [boxes[i, :counts[i]].copy() for i in range(n)]
