@@ -510,7 +510,7 @@ def v2_postprocess(bboxes, obj_probs, class_probs, image_shape=(416, 416), thres
     bboxes = bboxes.astype(np.int32)
     mm = [0, 0, image_shape[1] - 1, image_shape[0] - 1]
     bboxes = np.stack([np.maximum(bboxes[:, 0], mm[0]), np.maximum(bboxes[:, 1], mm[1]),
-                       np.minimum(bboxes[:, 2], mm[2]), np.minimum(bboxes[:, 3], mm[3])], axis=1)
+                       np.minimum(bboxes[:, 2], mm[2]), np.minimum(bboxes[:, 3], mm[3])], axis=1).astype(np.int32)
     obj = np.reshape(obj_probs, [-1])
     cls = np.reshape(class_probs, [len(obj), -1])
     cmax = np.argmax(cls, axis=1)

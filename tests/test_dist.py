@@ -1,0 +1,56 @@
+"""The N>1 path on CPU: two processes, gloo backend, sharded batch, one all-gather of detection records."""
+import os
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from yolo_tensorflow_amd import dist as ydist
+from yolo_tensorflow_amd.hip import BOX_DTYPE
+
+
+def test_shard_bounds_cover_batch():
+    for B in (1, 7, 32, 64):
+        for G in (1, 2, 3, 8):
+            spans = [ydist.shard_bounds(B, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _fake_boxes(img_index, max_out):
+    rng = np.random.default_rng(1000 + img_index)
+    cnt = int(rng.integers(0, max_out + 1))
+    b = np.zeros(max_out, dtype=BOX_DTYPE)
+    b["x0"][:cnt] = rng.random(cnt); b["y0"][:cnt] = rng.random(cnt); b["x1"][:cnt] = rng.random(cnt); b["y1"][:cnt] = rng.random(cnt)
+    b["score"][:cnt] = rng.random(cnt); b["cls"][:cnt] = rng.integers(0, 80, cnt)
+    return b, cnt
+
+
+def _worker(rank, world, port, B, max_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = ydist.shard_bounds(B, world, rank)
+    boxes = np.zeros((hi - lo, max_out), dtype=BOX_DTYPE); counts = np.zeros(hi - lo, np.int32)
+    for i in range(lo, hi):
+        boxes[i - lo], counts[i - lo] = _fake_boxes(i, max_out)
+    buf = torch.from_numpy(ydist.pack_records(boxes, counts, max_out))
+    full = ydist.all_gather_detections(buf, B)
+    q.put((rank, full.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process():
+    B, max_out, world = 7, 5, 2          # ragged split 4 + 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, max_out, q)) for r in range(world)]
+    for p in procs: p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(results[0], results[1]) and results[0].shape == (B, 1 + max_out * 6)
+    dets = ydist.unpack_records(results[0], BOX_DTYPE, max_out)
+    for i in range(B):
+        want, cnt = _fake_boxes(i, max_out)
+        assert len(dets[i]) == cnt and np.array_equal(dets[i], want[:cnt])

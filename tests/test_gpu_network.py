@@ -1,0 +1,214 @@
+"""Whole-network parity through the C ABI: golden vectors from the compiled reference (darknet semantics),
+the oracle in TF semantics, and size-independent properties at the BASELINE size (416x416, batch 32)."""
+import numpy as np
+import pytest
+from conftest import golden
+from oracle import yolo_ref as R
+from yolo_tensorflow_amd import darknet_io as IO
+
+pytestmark = pytest.mark.gpu
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("name", ["mini_v3.npz", "mini_v2.npz"])
+def test_mini_network_matches_compiled_reference_fp32(hiplib, name):
+    """Every layer output of the reference's own C forward pass (golden), fp32 device path, darknet semantics.
+    Tolerance 5e-4 of each tensor's scale: darknet's CPU batch-norm uses sqrt(var)+1e-6 where the folded
+    weights use sqrt(var+1e-5) and the summation order differs."""
+    g = golden(name)
+    eng = hiplib.Engine(str(g["cfg"]), max_batch=1, dtype=hiplib.FP32, semantics=hiplib.SEM_DARKNET, keep_layers=True)
+    eng.set_weights(g["weights"])
+    eng.forward(g["image_u8"][None], scale=1.0 / 255.0)
+    secs = IO.parse_cfg(str(g["cfg"]))
+    for i, s in enumerate(secs[1:]):
+        if s["type"] in ("yolo", "region"):
+            continue
+        got = eng.layer_output(i, 1)
+        ref = g["layer_%02d" % i]
+        assert got.shape == ref.shape
+        assert _relmax(got, ref) < 5e-4, "layer %d (%s)" % (i, s["type"])
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["mini_v3.npz", "mini_v2.npz"])
+def test_mini_network_bf16_tracks_reference(hiplib, name):
+    g = golden(name)
+    eng = hiplib.Engine(str(g["cfg"]), max_batch=1, dtype=hiplib.BF16, semantics=hiplib.SEM_DARKNET, keep_layers=True)
+    eng.set_weights(g["weights"])
+    eng.forward(g["image_u8"][None])
+    secs = IO.parse_cfg(str(g["cfg"]))
+    for i, s in enumerate(secs[1:]):
+        if s["type"] in ("yolo", "region"):
+            continue
+        # bf16 storage: 2^-8 relative per stored tensor, compounding over <= 13 layers
+        assert _relmax(eng.layer_output(i, 1), g["layer_%02d" % i]) < 3e-2, "layer %d" % i
+    eng.close()
+
+
+def test_mini_v3_boxes_match_darknet(hiplib):
+    """Decoded candidates == get_network_boxes of the compiled reference (fp32 path)."""
+    g = golden("mini_v3.npz")
+    eng = hiplib.Engine(str(g["cfg"]), max_batch=1, dtype=hiplib.FP32, semantics=hiplib.SEM_DARKNET)
+    eng.set_weights(g["weights"])
+    det = eng.forward(g["image_u8"][None])[0]
+    keep = det[:, 4] > float(g["thresh"])
+    assert keep.sum() == len(g["boxes_raw"])
+    np.testing.assert_allclose(det[keep, :4], g["boxes_raw"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(det[keep, 4], g["obj_raw"], rtol=2e-3, atol=2e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("cfg,size", [("yolov3", 96), ("yolov2", 96), ("yolov3-tiny", 96), ("yolov2-tiny-voc", 96)])
+def test_tf_semantics_network_vs_oracle(hiplib, cfg, size):
+    txt = IO.with_input_size(IO.cfg_text(cfg), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (2, size, size, 3), dtype=np.uint8)
+    x01 = img.astype(np.float32) / np.float32(255)
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    is_v3 = any(s["type"] == "yolo" for s in osecs)
+    for dtype, emu, tol in ((hiplib.FP32, False, 2e-4), (hiplib.BF16, True, 3e-2)):
+        eng = hiplib.Engine(txt, max_batch=2, dtype=dtype, keep_layers=True)
+        eng.set_weights(flat)
+        det = eng.forward(img)
+        heads, outs = R.forward(osecs, params, R.to_bf16(x01) if emu else x01, emulate_bf16=emu, collect=True)
+        for i, o in enumerate(outs):
+            if o is not None:
+                assert _relmax(eng.layer_output(i, 2), o) < tol, "%s layer %d dtype %d" % (cfg, i, dtype)
+        if is_v3:
+            ref = R.yolo_v3_detections(heads, size, ratio=True)
+        else:
+            s, raw = heads[0]
+            bx, ob, cl = R.region_decode(raw, R.yolo_anchors(s), int(s["classes"]))
+            b = bx.reshape(2, -1, 4)
+            ref = np.concatenate([np.stack([(b[..., 0] + b[..., 2]) / 2, (b[..., 1] + b[..., 3]) / 2, b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]], -1),
+                                  ob.reshape(2, -1, 1), cl.reshape(2, -1, cl.shape[-1])], -1)
+        assert det.shape == ref.shape
+        np.testing.assert_allclose(det, ref, rtol=tol * 10, atol=tol)
+        eng.close()
+
+
+def _iou(a, b):
+    ix = max(0.0, min(a[2], b[2]) - max(a[0], b[0])); iy = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+    inter = ix * iy
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter + 1e-12)
+
+
+@pytest.fixture(scope="module")
+def v3_416(hiplib):
+    txt = IO.cfg_text("yolov3")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    eng = hiplib.Engine(txt, max_batch=32)
+    eng.set_weights(flat)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (32, 416, 416, 3), dtype=np.uint8)
+    yield eng, txt, flat, img
+    eng.close()
+
+
+def test_full_size_boxes_vs_oracle_one_image(hiplib, v3_416):
+    """YOLOv3-416 (BASELINE config), one image: device boxes vs the fp32 oracle in TF semantics.
+    Stated tolerance: fp32 path IoU >= 0.999 and |dscore| <= 1e-3; bf16 path IoU >= 0.95 and |dscore| <= 3e-2 for
+    every oracle box whose score clears the threshold by more than that margin (threshold-flip band reported apart)."""
+    eng, txt, flat, img = v3_416
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    x01 = img[:1].astype(np.float32) / np.float32(255)
+    heads, _ = R.forward(osecs, params, x01)
+    ref = R.yolo_v3_detections(heads, 416, ratio=True)[0]
+    rb, rs, rc, ridx = R.select_threshold(ref, 0.5)
+    assert len(rs) > 5
+    for dtype, iou_min, ds in ((hiplib.FP32, 0.999, 1e-3), (hiplib.BF16, 0.95, 3e-2)):
+        e = eng if dtype == hiplib.BF16 else hiplib.Engine(txt, max_batch=1, dtype=hiplib.FP32)
+        if dtype == hiplib.FP32:
+            e.set_weights(flat)
+        det = e.forward(img[:1])[0]
+        gb, gs, gc, gidx = R.select_threshold(det, 0.5)
+        gmap = {int(r): k for k, r in enumerate(gidx)}
+        checked = 0
+        for k, r in enumerate(ridx):
+            if rs[k] < 0.5 + ds:
+                continue                      # may legitimately flip across the threshold
+            assert int(r) in gmap, "candidate row %d lost (score %.4f)" % (r, rs[k])
+            j = gmap[int(r)]
+            assert _iou(rb[k], gb[j]) >= iou_min and abs(rs[k] - gs[j]) <= ds
+            checked += 1
+        assert checked > 3
+        if dtype == hiplib.FP32:
+            e.close()
+
+
+def test_full_size_batch32_properties(hiplib, v3_416):
+    eng, txt, flat, img = v3_416
+    det = eng.forward(img)
+    assert det.shape == (32, 10647, 85) and np.isfinite(det).all()
+    # determinism: same input, same bits
+    assert np.array_equal(det, eng.forward(img))
+    # batch independence: an image alone == the same image inside the batch, bit for bit
+    for i in (0, 17, 31):
+        assert np.array_equal(eng.forward(img[i:i + 1])[0], det[i])
+    # ranges promised by the decode: sigmoid outputs in [0,1], centres inside the image, sizes positive
+    assert (det[..., 4:] >= 0).all() and (det[..., 4:] <= 1).all()
+    assert (det[..., 0:2] >= 0).all() and (det[..., 0:2] <= 1).all() and (det[..., 2:4] > 0).all()
+    # postprocess invariants (the API refuses to post-process more images than the last forward ran)
+    with pytest.raises(hiplib.YoloError, match="last forward"):
+        eng.postprocess(32)
+    eng.forward(img, want_detections=False)
+    res = eng.postprocess(32, score_thr=0.5, iou_thr=0.5, max_out=20)
+    for b, r in enumerate(res):
+        assert len(r) <= 20
+        assert (np.diff(r["score"]) <= 0).all() and (r["score"] > 0.5).all()
+        for i in range(len(r)):
+            for j in range(i):
+                bi = (r["x0"][i], r["y0"][i], r["x1"][i], r["y1"][i]); bj = (r["x0"][j], r["y0"][j], r["x1"][j], r["y1"][j])
+                assert _iou(bi, bj) <= 0.5 + 1e-5
+        # and equal to the oracle's tail applied to the device's own decoded tensor (bit-exact)
+        ob, os_, oc = R.detect_v3_tf(det[b], 0.5, 0.5, 20)
+        assert np.array_equal(r["score"], os_) and np.array_equal(r["cls"], oc)
+
+
+def test_device_resident_input_and_u8_resize(hiplib, v3_416):
+    import torch
+    eng, txt, flat, img = v3_416
+    host = eng.forward(img[:4])
+    dev = eng.forward(torch.from_numpy(img[:4]).cuda())
+    assert np.array_equal(host, dev)
+    f32 = eng.forward(img[:4].astype(np.float32))             # `inputs / 255` on float input (V3/yolo_v3.py:215)
+    assert np.array_equal(host, f32)
+    # arbitrary-size uint8 image: on-device legacy bilinear == oracle resize then forward
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (576, 768, 3), dtype=np.uint8)
+    a = eng.forward_image(big)
+    pre = R.input_process(big, 416)                            # [1,416,416,3] float 0..1
+    b = eng.forward(np.ascontiguousarray(pre), scale=1.0)
+    assert np.abs(a - b).max() < 2e-2                          # bf16 input rounding of 1-ulp-different pixels
+
+
+def test_errors_are_codes_not_exits(hiplib):
+    eng = hiplib.Engine(IO.cfg_text("yolov3-tiny"), max_batch=2)
+    with pytest.raises(hiplib.YoloError, match="before weights"):
+        eng.forward(np.zeros((1, 416, 416, 3), np.uint8))
+    with pytest.raises(hiplib.YoloError, match="floats"):
+        eng.set_weights(np.zeros(10, np.float32))
+    with pytest.raises(hiplib.YoloError, match="cannot open"):
+        eng.load_weights("/nonexistent/yolov3.weights")
+    eng.set_weights(IO.synth_weights(IO.parse_cfg(IO.cfg_text("yolov3-tiny")), 0))
+    with pytest.raises(hiplib.YoloError, match="batch"):
+        eng.forward(np.zeros((3, 416, 416, 3), np.uint8))
+    with pytest.raises(hiplib.YoloError):
+        hiplib.Engine("[net]\nwidth=416\nheight=416\nchannels=3\n[softmax]\n", max_batch=1)
+    eng.close()
+
+
+def test_weights_file_loader(hiplib, tmp_path):
+    txt = IO.with_input_size(IO.cfg_text("yolov3-tiny"), 96)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 0)
+    img = np.random.default_rng(0).integers(0, 256, (1, 96, 96, 3), dtype=np.uint8)
+    a = hiplib.Engine(txt); a.set_weights(flat); ref = a.forward(img); a.close()
+    for mj, mn, hdr in ((0, 2, 0), (0, 1, 0), (0, 2, 5), (0, 1, 4)):
+        p = str(tmp_path / "w.weights"); IO.write_weights_file(p, flat, mj, mn)
+        b = hiplib.Engine(txt); b.load_weights(p, hdr)
+        assert np.array_equal(b.forward(img), ref)
+        b.close()

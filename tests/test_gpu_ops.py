@@ -1,0 +1,241 @@
+"""Parity of every production kernel, called through the C ABI (yolo_op_*), against the oracle on the same
+seeded inputs.  Integer/index results (kept sets, labels, copies) are bit-exact; floating point tolerances
+are stated next to each check."""
+import numpy as np
+import pytest
+from conftest import golden
+from oracle import yolo_ref as R
+
+pytestmark = pytest.mark.gpu
+
+# the 23 unique (k, stride, H, Cin, Cout) conv shapes of YOLOv3-416
+V3_SHAPES = [
+    (3, 1, 416, 3, 32), (3, 2, 416, 32, 64), (1, 1, 208, 64, 32), (3, 1, 208, 32, 64), (3, 2, 208, 64, 128),
+    (1, 1, 104, 128, 64), (3, 1, 104, 64, 128), (3, 2, 104, 128, 256), (1, 1, 52, 256, 128), (1, 1, 52, 384, 128),
+    (1, 1, 52, 256, 255), (3, 1, 52, 128, 256), (3, 2, 52, 256, 512), (1, 1, 26, 512, 256), (1, 1, 26, 768, 256),
+    (1, 1, 26, 512, 255), (1, 1, 26, 256, 128), (3, 1, 26, 256, 512), (3, 2, 26, 512, 1024), (1, 1, 13, 1024, 512),
+    (1, 1, 13, 1024, 255), (1, 1, 13, 512, 256), (3, 1, 13, 512, 1024),
+]
+
+
+def _conv_case(rng, k, s, h, cin, cout, n=2, residual=False):
+    h = min(h, 26 if cin * cout < 65536 else 13)
+    if s == 2:
+        h += h % 2
+    x = R.to_bf16(rng.standard_normal((n, h, h, cin)).astype(np.float32))
+    w = R.to_bf16((rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = R.leaky_relu(R.conv2d_nhwc(x, w, s) + b)
+    res = None
+    if residual:
+        res = R.to_bf16(rng.standard_normal(ref.shape).astype(np.float32))
+        ref = R.to_bf16(ref) + res
+    return x, w, b, res, ref
+
+
+def _assert_bf16_close(got, ref, scale=None):
+    # both operands are bf16-exact, accumulation is fp32: the only differences are summation order and the
+    # final round to bf16 -> at most one bf16 ulp (2^-8 relative) plus slack for cancellation near zero.
+    # `scale`: magnitude the ulp refers to when the result is a sum of separately rounded terms (residual).
+    want = R.to_bf16(ref)
+    err = np.abs(got - want)
+    tol = 2.0 ** -7 * (np.abs(want) if scale is None else scale) + 2e-3
+    assert (err <= tol).all(), "max err %.3e at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("shape", V3_SHAPES, ids=lambda s: "k%d_s%d_h%d_%dto%d" % s)
+def test_conv_bf16_all_yolov3_shapes(hiplib, shape):
+    k, s, h, cin, cout = shape
+    rng = np.random.default_rng(hash(shape) % 2 ** 32)
+    x, w, b, _, ref = _conv_case(rng, k, s, h, cin, cout)
+    got = hiplib.op_conv2d(x, w, b, stride=s, act=1)
+    assert got.shape == ref.shape
+    _assert_bf16_close(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 26, 64, 128), (1, 1, 13, 1024, 255), (3, 2, 26, 32, 64), (3, 1, 20, 3, 32)],
+                         ids=lambda s: "k%d_s%d_h%d_%dto%d" % s)
+def test_conv_bf16_every_tile_config_agrees(hiplib, shape):
+    k, s, h, cin, cout = shape
+    rng = np.random.default_rng(7)
+    x, w, b, _, ref = _conv_case(rng, k, s, h, cin, cout, n=3)
+    outs = [hiplib.op_conv2d(x, w, b, stride=s, act=1, tile_cfg=c) for c in range(hiplib.op_conv_num_cfgs())]
+    _assert_bf16_close(outs[0], ref)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])       # same K order in every tiling -> bit-identical
+
+
+def test_conv_bf16_residual_and_linear(hiplib):
+    rng = np.random.default_rng(9)
+    x, w, b, res, ref = _conv_case(rng, 3, 1, 26, 64, 128, residual=True)
+    _assert_bf16_close(hiplib.op_conv2d(x, w, b, act=1, residual=res), ref, scale=np.abs(ref - res) + np.abs(res))
+    lin = R.conv2d_nhwc(x, w, 1) + b
+    _assert_bf16_close(hiplib.op_conv2d(x, w, b, act=0), lin)
+    _assert_bf16_close(hiplib.op_conv2d(x, w, None, act=0), R.conv2d_nhwc(x, w, 1))
+
+
+def test_conv_ragged_edges(hiplib):
+    """pixel count and channel count not multiples of any tile; single pixel; batch 1."""
+    rng = np.random.default_rng(10)
+    for (n, h, cin, cout, k, s) in ((1, 1, 8, 8, 1, 1), (1, 7, 24, 40, 3, 1), (3, 9, 16, 72, 3, 2), (1, 5, 8, 255, 1, 1)):
+        x = R.to_bf16(rng.standard_normal((n, h, h, cin)).astype(np.float32))
+        w = R.to_bf16(rng.standard_normal((k, k, cin, cout)).astype(np.float32) * 0.2)
+        got = hiplib.op_conv2d(x, w, None, stride=s, act=0)
+        _assert_bf16_close(got, R.conv2d_nhwc(x, w, s))
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 26, 64, 128), (1, 1, 13, 512, 255), (3, 2, 26, 32, 64), (3, 1, 20, 3, 32), (3, 1, 13, 256, 512)],
+                         ids=lambda s: "k%d_s%d_h%d_%dto%d" % s)
+def test_conv_fp32_exact_path(hiplib, shape):
+    """f32-input MFMA: only summation order differs from the fp32 oracle -> rtol 1e-4 of the tensor scale."""
+    k, s, h, cin, cout = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, h, h, cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((2, (h + 2 * (k // 2) - k) // s + 1, (h + 2 * (k // 2) - k) // s + 1, cout)).astype(np.float32)
+    ref = R.leaky_relu(R.conv2d_nhwc(x, w, s) + b) + res
+    got = hiplib.op_conv2d(x, w, b, stride=s, act=1, residual=res, dtype=hiplib.FP32)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_upsample(hiplib):
+    rng = np.random.default_rng(12)
+    for shape in ((2, 13, 13, 256), (1, 26, 26, 128), (1, 1, 1, 8), (3, 5, 7, 16)):
+        x = R.to_bf16(rng.standard_normal(shape).astype(np.float32))
+        # TF bilinear `_upsample`: same fp32 lerp order as the oracle, rounded once to bf16 -> bit-exact
+        assert np.array_equal(hiplib.op_upsample2x(x, hiplib.SEM_TF), R.to_bf16(R.upsample_tf(x)))
+        assert np.array_equal(hiplib.op_upsample2x(x, hiplib.SEM_DARKNET), R.upsample_nearest(x))
+
+
+def test_reorg_and_maxpool(hiplib):
+    rng = np.random.default_rng(13)
+    x = R.to_bf16(rng.standard_normal((2, 26, 26, 64)).astype(np.float32))
+    assert np.array_equal(hiplib.op_reorg(x, 2, hiplib.SEM_TF), R.space_to_depth(x, 2))
+    assert np.array_equal(hiplib.op_reorg(x, 2, hiplib.SEM_DARKNET), R.reorg_darknet(x, 2))
+    for shape in ((2, 26, 26, 64), (1, 13, 13, 512), (1, 7, 7, 8)):
+        x = R.to_bf16(rng.standard_normal(shape).astype(np.float32))
+        if shape[1] % 2 == 0:
+            assert np.array_equal(hiplib.op_maxpool(x, 2, 2), R.max_pool(x, 2, 2))
+        assert np.array_equal(hiplib.op_maxpool(x, 2, 1), R.max_pool(x, 2, 1))     # 'SAME' stride-1 pool, -inf padding
+
+
+def test_resize_u8_legacy_bilinear(hiplib):
+    rng = np.random.default_rng(14)
+    for (h, w, s) in ((576, 768, 416), (37, 91, 64), (416, 416, 416), (900, 1352, 608)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = hiplib.op_resize_u8(img, s)
+        ref = R.input_process(img, s)[0]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)      # same op order; a 1-ulp slack on the scale factor
+
+
+@pytest.mark.parametrize("mode", ["ratio", "pixel"])
+def test_decode_yolo(hiplib, mode):
+    rng = np.random.default_rng(15)
+    anchors = [(116, 90), (156, 198), (373, 326)]
+    for g in (13, 26):
+        raw = (rng.standard_normal((2, g, g, 255)) * 2).astype(np.float32)
+        fn = R.detection_layer_ratio if mode == "ratio" else R.detection_layer_pixel
+        ref = fn(raw, anchors, (32 * g, 32 * g))
+        got = hiplib.op_decode(raw, anchors, 80, 32 * g, hiplib.DECODE_RATIO if mode == "ratio" else hiplib.DECODE_PIXEL)
+        # expf/sigmoid differ from numpy's by a few ulp
+        np.testing.assert_allclose(got, ref, rtol=3e-6, atol=1e-7)
+
+
+def test_decode_region(hiplib):
+    rng = np.random.default_rng(16)
+    anchors = [(0.57273, 0.677385), (1.87446, 2.06253), (3.33843, 5.47434), (7.88282, 3.52778), (9.77052, 9.16828)]
+    raw = (rng.standard_normal((2, 13, 13, 425)) * 2).astype(np.float32)
+    boxes, obj, cls = R.region_decode(raw, anchors, 80)
+    got = hiplib.op_decode(raw, anchors, 80, 416, region=True).reshape(2, 169, 5, 85)
+    corners = np.stack([got[..., 0] - got[..., 2] / 2, got[..., 1] - got[..., 3] / 2,
+                        got[..., 0] + got[..., 2] / 2, got[..., 1] + got[..., 3] / 2], -1)
+    np.testing.assert_allclose(corners, boxes, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[..., 4], obj, rtol=3e-6)
+    np.testing.assert_allclose(got[..., 5:], cls, rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _planted(rng, n, rows, classes, clusters=10, per=8, unit=1.0):
+    det = np.zeros((n, rows, 5 + classes), np.float32)
+    det[..., 0:2] = rng.uniform(0.1, 0.9, (n, rows, 2)) * unit
+    det[..., 2:4] = rng.uniform(0.02, 0.3, (n, rows, 2)) * unit
+    det[..., 4] = rng.uniform(0, 0.45, (n, rows))
+    det[..., 5:] = rng.uniform(0, 1, (n, rows, classes))
+    for b in range(n):
+        idx = rng.permutation(rows)[:clusters * per].reshape(clusters, per)
+        for c in range(clusters):
+            cx, cy, w, h = rng.uniform(0.2, 0.8) * unit, rng.uniform(0.2, 0.8) * unit, rng.uniform(0.1, 0.3) * unit, rng.uniform(0.1, 0.3) * unit
+            cls = rng.integers(0, classes)
+            for r in idx[c]:
+                det[b, r, :4] = [cx + rng.normal(0, .01) * unit, cy + rng.normal(0, .01) * unit, w + rng.normal(0, .01) * unit, h + rng.normal(0, .01) * unit]
+                det[b, r, 4] = rng.uniform(0.6, 1)
+                det[b, r, 5:] = rng.uniform(0, 0.3, classes); det[b, r, 5 + cls] = rng.uniform(0.85, 1)
+    return det.astype(np.float32)
+
+
+def _check_tf(hiplib, det, thr, iou, max_out):
+    got = hiplib.op_postprocess(det, thr, iou, max_out, hiplib.NMS_TF, hiplib.SELECT_GT)
+    for b in range(det.shape[0]):
+        boxes, scores, classes = R.detect_v3_tf(det[b], thr, iou, max_out)
+        g = got[b]
+        assert len(g) == len(scores)
+        assert np.array_equal(g["score"], scores) and np.array_equal(g["cls"], classes)
+        assert np.array_equal(np.stack([g["x0"], g["y0"], g["x1"], g["y1"]], -1).reshape(-1, 4), boxes.reshape(-1, 4))
+    return got
+
+
+def test_postprocess_tf_nms_bit_exact(hiplib):
+    rng = np.random.default_rng(17)
+    det = _planted(rng, 3, 10647, 80)
+    got = _check_tf(hiplib, det, 0.5, 0.5, 20)
+    assert all(5 <= len(g) <= 20 for g in got)
+    _check_tf(hiplib, det, 0.4, 0.4, 10)          # the converter's flags (D2T ...py:42-44)
+    _check_tf(hiplib, det, 0.5, 0.5, 3)           # max_output_size cap
+    _check_tf(hiplib, det, 0.999999, 0.5, 20)     # nothing passes -> empty
+
+
+def test_postprocess_edge_cases(hiplib):
+    rng = np.random.default_rng(18)
+    # every candidate passes (sort > LDS capacity -> global-memory sort path), ties in score
+    det = _planted(rng, 1, 6000, 4, clusters=40, per=20)
+    det[..., 4] = np.maximum(det[..., 4], 0.7); det[..., 5] = 0.9
+    det[0, 100:200, 4] = 0.8; det[0, 100:200, 5:] = 0.5; det[0, 100:200, 5] = 1.0     # 100-way tie
+    _check_tf(hiplib, det, 0.1, 0.5, 50)
+    # a single row; rows that are not a multiple of the workgroup
+    _check_tf(hiplib, _planted(rng, 2, 1, 3, clusters=1, per=1), 0.3, 0.5, 5)
+    _check_tf(hiplib, _planted(rng, 2, 1025, 3), 0.3, 0.5, 100)
+    # degenerate (zero-area) boxes never suppress each other
+    d = _planted(rng, 1, 64, 2, clusters=2, per=4); d[..., 2] = 0
+    _check_tf(hiplib, d, 0.3, 0.5, 64)
+
+
+def test_postprocess_darknet_per_class(hiplib):
+    rng = np.random.default_rng(19)
+    det = _planted(rng, 2, 2028, 20, clusters=12, per=6)
+    got = hiplib.op_postprocess(det, 0.5, 0.45, 400, hiplib.NMS_DARKNET, hiplib.SELECT_GT)
+    for b in range(2):
+        _, scores, labels, idx = R.select_threshold(det[b], 0.5)
+        probs = np.zeros((len(idx), 20), np.float32); probs[np.arange(len(idx)), labels] = scores
+        kept = R.dn_nms_sort(det[b, idx, :4], probs, 0.45)
+        want = sorted((float(kept[i, labels[i]]), int(labels[i])) for i in range(len(idx)) if kept[i, labels[i]] > 0)
+        have = sorted((float(s), int(c)) for s, c in zip(got[b]["score"], got[b]["cls"]))
+        assert have == want and len(have) > 0
+
+
+def test_postprocess_v2_numpy_flavour(hiplib):
+    """V2 utils.postprocess: int32 pixel boxes, clip, score > thr, top-400, class-aware NMS in float64.
+    The oracle restatement is pinned bit-for-bit to the reference by tests/test_oracle_golden.py."""
+    rng = np.random.default_rng(20)
+    det = _planted(rng, 2, 845, 80, clusters=10, per=9)
+    h, w = 576, 768
+    got = hiplib.op_postprocess(det, 0.5, 0.5, 400, hiplib.NMS_PER_CLASS, hiplib.SELECT_GT, image_hw=(h, w))
+    for b in range(2):
+        d = det[b]
+        corners = np.stack([d[:, 0] - d[:, 2] * np.float32(.5), d[:, 1] - d[:, 3] * np.float32(.5),
+                            d[:, 0] + d[:, 2] * np.float32(.5), d[:, 1] + d[:, 3] * np.float32(.5)], -1)
+        bb, ss, cc = R.v2_postprocess(corners, d[:, 4], d[:, 5:], image_shape=(h, w), threshold=0.5)
+        g = got[b]
+        assert len(g) == len(ss) > 0
+        assert np.array_equal(g["score"], ss.astype(np.float32)) and np.array_equal(g["cls"], cc)
+        assert np.array_equal(np.stack([g["x0"], g["y0"], g["x1"], g["y1"]], -1).astype(np.int32), bb)

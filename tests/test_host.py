@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: topology files, .weights streams, the C-ABI library's exports."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+from conftest import ROOT, has_gpu
+from yolo_tensorflow_amd import darknet_io as IO
+
+
+def test_yolov3_topology_matches_reference_tables():
+    secs = IO.parse_cfg(IO.cfg_text("yolov3"))
+    shapes = IO.layer_shapes(secs)
+    assert len(shapes) == 107                                   # V3/yolov3.txt: layers 0..106
+    convs = IO.conv_specs(secs)
+    assert len(convs) == 75
+    flops = 0.0
+    for c in convs:
+        t, H, W, C, cin = shapes[c["index"]]
+        flops += 2.0 * c["size"] ** 2 * cin * C * H * W
+    assert abs(flops / 1e9 - 65.86) < 0.01                      # V3/yolov3.txt sum == darknet numops
+    assert IO.weights_count(secs) == 62001757                   # yolov3.weights payload (248 MB / 4 - header)
+    assert shapes[36][1:4] == (52, 52, 256) and shapes[61][1:4] == (26, 26, 512) and shapes[86][1:4] == (26, 26, 768)
+    assert shapes[98][1:4] == (52, 52, 384)
+    rows = sum(s[1] * s[2] * 3 for s in shapes if s[0] == "yolo")
+    assert rows == 10647
+    secs608 = IO.parse_cfg(IO.cfg_text("yolov3-608"))
+    assert sum(s[1] * s[2] * 3 for s in IO.layer_shapes(secs608) if s[0] == "yolo") == 22743
+
+
+def test_yolov2_topology_matches_reference_tables():
+    secs = IO.parse_cfg(IO.cfg_text("yolov2"))
+    shapes = IO.layer_shapes(secs)
+    assert len(shapes) == 32 and shapes[28][1:4] == (13, 13, 1280) and shapes[30][1:4] == (13, 13, 425)
+    flops = sum(2.0 * c["size"] ** 2 * shapes[c["index"]][4] * shapes[c["index"]][3] * shapes[c["index"]][1] * shapes[c["index"]][2]
+                for c in IO.conv_specs(secs))
+    assert abs(flops / 1e9 - 29.46) < 0.02                      # V2/yolov2.txt
+    assert IO.default_header(secs) == (0, 1)
+
+
+def test_weights_file_round_trip(tmp_path):
+    secs = IO.parse_cfg(IO.cfg_text("yolov3-tiny"))
+    flat = IO.synth_weights(secs, seed=3)
+    assert flat.size == IO.weights_count(secs)
+    for (mj, mn, hdr) in ((0, 2, 5), (0, 1, 4)):
+        p = str(tmp_path / ("w%d.weights" % hdr))
+        IO.write_weights_file(p, flat, mj, mn, 0, seen=12345)
+        assert os.path.getsize(p) == hdr * 4 + flat.size * 4
+        back, ver = IO.read_weights_file(p)
+        assert ver == (mj, mn, 0, 12345) and np.array_equal(back, flat)
+        back2, _ = IO.read_weights_file(p, header_ints=hdr)
+        assert np.array_equal(back2, flat)
+    assert np.array_equal(IO.synth_weights(secs, seed=3), flat)          # seeded => reproducible
+
+
+def test_with_input_size():
+    secs = IO.parse_cfg(IO.with_input_size(IO.cfg_text("yolov3"), 608))
+    assert secs[0]["width"] == "608" and IO.layer_shapes(secs)[-1][1] == 76
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yolo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a CPU-only box and exports exactly what include/yolo_hip.h declares."""
+    from yolo_tensorflow_amd import hip
+    lib = hip.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "libyolo_hip.so does not export " + name
+    assert sorted(hip.EXPORTS) == declared
+    assert ctypes.sizeof(hip._Config) == 48 and hip.BOX_DTYPE.itemsize == 24
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback_without_device():
+    from yolo_tensorflow_amd import hip
+    with pytest.raises(hip.YoloError, match="no HIP device|hipSetDevice|HIP"):
+        hip.Engine(IO.cfg_text("yolov3-tiny"), max_batch=1)
+    with pytest.raises(hip.YoloError):
+        hip.op_upsample2x(np.zeros((1, 2, 2, 8), np.float32))
+
+
+def test_create_rejects_bad_config():
+    from yolo_tensorflow_amd import hip
+    lib = hip.load_library()
+    err = ctypes.create_string_buffer(256)
+    assert lib.yolo_create(None, err, 256) is None and b"yolo_config" in err.value
+    conf = hip._Config(ctypes.sizeof(hip._Config), b"[net]\nwidth=32\nheight=32\nchannels=3\n", 0, 0, 0, 0, 0, 0, None)
+    assert lib.yolo_create(ctypes.byref(conf), err, 256) is None and b"max_batch" in err.value

@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (it reads /root/reference and oracle/_ref); the outputs are small
+`.npz` data files (inputs + expected outputs), never reference source text.
+
+  nms_v3_numpy.npz   inputs/outputs of the reference's numpy `non_max_suppression` + `_iou`
+                     (V3/yolo_v3.py:350-420), imported with stub `tensorflow` modules
+  v2_postprocess.npz inputs/outputs of V2 `postprocess` / `bboxes_iou` (V2/utils.py:30-187), imported
+                     with stub `cv2` (and np.bool shim)
+  mini_v3.npz / mini_v2.npz
+                     a small darknet topology covering every hot-path layer type, its synthetic weights,
+                     an input image, EVERY layer output, and the boxes after get_network_boxes /
+                     do_nms_sort -- produced by the reference's own C code compiled CPU-only
+                     (oracle/Makefile -> oracle/_ref/libdarknet_ref.so)
+"""
+import os
+import sys
+import types
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+MINI_V3 = """[net]
+batch=1
+width=64
+height=64
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=8
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=16
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=8
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=16
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=1
+
+[convolutional]
+batch_normalize=1
+filters=16
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=27
+activation=linear
+
+[yolo]
+mask=3,4,5
+anchors=4,5,  8,6,  10,14,  20,18,  30,40,  50,44
+classes=4
+num=6
+
+[route]
+layers=-3
+
+[convolutional]
+batch_normalize=1
+filters=8
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[upsample]
+stride=2
+
+[route]
+layers=-1,5
+
+[convolutional]
+batch_normalize=1
+filters=24
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=27
+activation=linear
+
+[yolo]
+mask=0,1,2
+anchors=4,5,  8,6,  10,14,  20,18,  30,40,  50,44
+classes=4
+num=6
+"""
+
+MINI_V2 = """[net]
+batch=1
+width=64
+height=64
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=8
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+batch_normalize=1
+filters=16
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+batch_normalize=1
+filters=16
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[route]
+layers=-4
+
+[convolutional]
+batch_normalize=1
+filters=8
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[reorg]
+stride=2
+
+[route]
+layers=-1,-4
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=30
+activation=linear
+
+[region]
+anchors=0.6,0.7,  1.9,2.1,  3.3,5.5
+bias_match=1
+classes=5
+coords=4
+num=3
+softmax=1
+"""
+
+
+def stub_modules():
+    tf = types.ModuleType("tensorflow")
+    contrib = types.ModuleType("tensorflow.contrib")
+    slim = types.ModuleType("tensorflow.contrib.slim")
+    fw = types.ModuleType("tensorflow.contrib.framework")
+    fw.add_arg_scope = lambda f: f
+    contrib.slim = slim; contrib.framework = fw; tf.contrib = contrib
+    sys.modules.update({"tensorflow": tf, "tensorflow.contrib": contrib, "tensorflow.contrib.slim": slim,
+                        "tensorflow.contrib.framework": fw, "cv2": types.ModuleType("cv2")})
+    if not hasattr(np, "bool"):
+        np.bool = bool
+
+
+def planted_detections(rng, n_img, rows, classes, clusters=6, per=7, size=416.0):
+    """[n,rows,5+C] with clusters of jittered boxes (corners, pixels) so NMS has real work."""
+    det = np.zeros((n_img, rows, 5 + classes), dtype=np.float32)
+    det[..., :4] = rng.uniform(0, size, (n_img, rows, 4)).astype(np.float32)
+    det[..., 4] = rng.uniform(0.0, 0.3, (n_img, rows)).astype(np.float32)
+    det[..., 5:] = rng.uniform(0.01, 1, (n_img, rows, classes)).astype(np.float32)
+    for b in range(n_img):
+        r = 0
+        for c in range(clusters):
+            cx, cy = rng.uniform(60, size - 60, 2); w, h = rng.uniform(30, 120, 2)
+            cls = int(rng.integers(0, classes))
+            for _ in range(per):
+                j = rng.normal(0, 6, 4)
+                det[b, r, :4] = [cx - w / 2 + j[0], cy - h / 2 + j[1], cx + w / 2 + j[2], cy + h / 2 + j[3]]
+                det[b, r, 4] = rng.uniform(0.55, 0.999)
+                det[b, r, 5:] = rng.uniform(0.01, 0.3, classes); det[b, r, 5 + cls] = rng.uniform(0.7, 1.0)
+                r += 1
+    perm = rng.permutation(rows)
+    return det[:, perm]
+
+
+def gen_nms_v3():
+    sys.path.insert(0, os.path.join(REF, "YOLO_V3", "YOLOv3-Tensorflow-detect-export"))
+    import yolo_v3 as ref
+    rng = np.random.default_rng(2)
+    det = planted_detections(rng, 2, 300, 6)
+    res = ref.non_max_suppression(det, confidence_threshold=0.5, iou_threshold=0.4)
+    keys = sorted(res.keys())
+    boxes = [np.array([b for b, _ in res[k]], dtype=np.float32) for k in keys]
+    scores = [np.array([s for _, s in res[k]], dtype=np.float32) for k in keys]
+    pairs = rng.uniform(0, 100, (64, 2, 4)).astype(np.float32)
+    ious = np.array([ref._iou(p[0], p[1]) for p in pairs], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "nms_v3_numpy.npz"), det=det, conf=0.5, iou=0.4, classes=np.array(keys),
+                        counts=np.array([len(b) for b in boxes]), boxes=np.concatenate(boxes), scores=np.concatenate(scores),
+                        pairs=pairs, pair_ious=ious)
+    print("nms_v3_numpy:", {int(k): len(res[k]) for k in keys})
+
+
+def gen_v2_post():
+    sys.path.insert(0, os.path.join(REF, "YOLO_V2", "YOLOv2-Tensorflow-detect-export"))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "YOLO_V2", "YOLOv2-Tensorflow-detect-export"))   # config.py reads ./yolo2_data at import
+    import utils as ref
+    os.chdir(cwd)
+    rng = np.random.default_rng(3)
+    n = 13 * 13 * 5
+    # normalised corner boxes with planted overlapping clusters
+    cx = rng.uniform(0.1, 0.9, n); cy = rng.uniform(0.1, 0.9, n); w = rng.uniform(0.02, 0.5, n); h = rng.uniform(0.02, 0.5, n)
+    for c in range(8):
+        base = c * 9
+        cx[base:base + 9] = cx[base] + rng.normal(0, .01, 9); cy[base:base + 9] = cy[base] + rng.normal(0, .01, 9)
+        w[base:base + 9] = w[base] + rng.normal(0, .01, 9); h[base:base + 9] = h[base] + rng.normal(0, .01, 9)
+    bboxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1).astype(np.float32).reshape(1, 169, 5, 4)
+    obj = rng.uniform(0, 0.4, n).astype(np.float32); obj[:72] = rng.uniform(0.7, 1, 72)
+    cls = rng.dirichlet(np.ones(80) * 0.05, n).astype(np.float32)
+    for c in range(8):
+        v = rng.uniform(0.0, 0.01, 80); v[int(rng.integers(0, 80))] = 0.9
+        cls[c * 9:(c + 1) * 9] = (v / v.sum()).astype(np.float32)
+    # two overlapping clusters of DIFFERENT classes must both survive (V2/utils.py:183)
+    cx[72:81] = cx[0] + rng.normal(0, .01, 9); cy[72:81] = cy[0] + rng.normal(0, .01, 9)
+    w[72:81] = w[0]; h[72:81] = h[0]; obj[72:81] = rng.uniform(0.7, 1, 9)
+    v = rng.uniform(0.0, 0.01, 80); v[(int(np.argmax(cls[0])) + 1) % 80] = 0.9
+    cls[72:81] = (v / v.sum()).astype(np.float32)
+    bboxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1).astype(np.float32).reshape(1, 169, 5, 4)
+    out_b, out_s, out_c = ref.postprocess(bboxes.copy(), obj.reshape(1, 169, 5).copy(), cls.reshape(1, 169, 5, 80).copy(),
+                                          image_shape=(576, 768), threshold=0.5)
+    ib = rng.integers(0, 400, (40, 4)).astype(np.int32); ib[:, 2:] += ib[:, :2]
+    with np.errstate(all="ignore"):
+        pair_iou = ref.bboxes_iou(ib[0], ib[1:])
+    np.savez_compressed(os.path.join(OUT, "v2_postprocess.npz"), bboxes=bboxes, obj=obj.reshape(1, 169, 5),
+                        cls=cls.reshape(1, 169, 5, 80), image_shape=np.array([576, 768]), threshold=0.5,
+                        out_boxes=out_b, out_scores=out_s, out_classes=out_c, int_boxes=ib, int_ious=pair_iou)
+    print("v2_postprocess: kept", len(out_s))
+
+
+def gen_mini(name, cfg, classes, nms_thresh=0.3, thresh=0.15):
+    from oracle import darknet_ref as D
+    from yolo_tensorflow_amd import darknet_io as IO
+    secs = IO.parse_cfg(cfg)
+    flat = IO.synth_weights(secs, seed=7, obj_bias=0.5)
+    mj, mn = IO.default_header(secs)
+    net = D.RefNet(cfg, flat, mj, mn)
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    x = img.astype(np.float32) / np.float32(255.0)
+    net.predict(x)
+    data = {"cfg": np.array(cfg), "weights": flat, "image_u8": img, "header": np.array([mj, mn])}
+    for i in range(net.n):
+        data["layer_%02d" % i] = net.layer_output_nhwc(i).astype(np.float32)
+    bb, obj, pr = net.boxes(thresh, None, classes)
+    data["boxes_raw"], data["obj_raw"], data["prob_raw"] = bb, obj, pr
+    net.predict(x)
+    bb2, obj2, pr2 = net.boxes(thresh, nms_thresh, classes)
+    data["boxes_nms"], data["obj_nms"], data["prob_nms"] = bb2, obj2, pr2
+    data["thresh"] = np.float32(thresh); data["nms"] = np.float32(nms_thresh)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print(name, "layers", net.n, "boxes", len(bb), "nonzero probs before/after nms", int((pr > 0).sum()), int((pr2 > 0).sum()))
+    net.close()
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    stub_modules()
+    gen_nms_v3()
+    gen_v2_post()
+    gen_mini("mini_v3", MINI_V3, 4)
+    gen_mini("mini_v2", MINI_V2, 5)

@@ -29,6 +29,9 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 template <int WP, int WC, int TP, int TC, bool OUT_F32>
 __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a)
 {
@@ -46,20 +49,28 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpi = wid % WP, wci = wid / WP;
 
+    // XCD-aware tile assignment: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles ordered pixel-tile-major so that its resident workgroups re-use the same
+    // activation rows (all channel tiles of a pixel tile) and walk the filter slices together.
     const int M = a.N * a.Ho * a.Wo;
     const int tilesC = (a.Cout + BC - 1) / BC;
-    const int ct = blockIdx.x % tilesC;
-    const int pt = blockIdx.x / tilesC;
+    const int tilesP = (M + BP - 1) / BP;
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= tilesP * tilesC) return;
+    const int ct = tile % tilesC;
+    const int pt = tile / tilesC;
 
     const bf16_t *__restrict__ in = (const bf16_t *)a.in;
     const bf16_t *__restrict__ wt = (const bf16_t *)a.wt;
 
-    // ---- per-thread staging geometry ----
-    const int chunk = tid & 7;
+    // ---- per-thread staging geometry: this thread always fetches LDS slot (row r0 + i*RPP, physical
+    //      chunk tid&7), i.e. logical K-chunk (tid&7) ^ (row&7) of that row (rule: swizzle the SOURCE) ----
     const int r0 = tid >> 3;
+    const int chunk = (tid & 7) ^ (r0 & 7);
     int pixbase[LA], iy0[LA], ix0[LA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
@@ -86,36 +97,27 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     int kc = chunk * 8, tap = 0;
     while (kc >= a.Cin_pad) { kc -= a.Cin_pad; ++tap; }
 
-    uint4 ra[LA], rb[LB];
-    auto load_global = [&](int kt) {
+    // global -> LDS direct (global_load_lds_dwordx4): one wave instruction fills 8 tile rows (1 KiB)
+    auto stage = [&](int kt, int buf) {
         int kh = 0, kw = 0;
         if (a.ksize == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
         else if (a.ksize != 1) { kh = tap / a.ksize; kw = tap - kh * a.ksize; }
         const bool tap_ok = tap < KK;
+        char *dx = sX + buf * (BP * 128) + wid * 1024;
+        char *dw = sW + buf * (BC * 128) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             int iy = iy0[i] + kh, ix = ix0[i] + kw;
             bool ok = tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const bf16_t *p = ok ? in + ((size_t)(pixbase[i] + iy * a.W + ix) * a.in_stride + kc)
                                  : (const bf16_t *)a.zeros;
-            ra[i] = *(const uint4 *)p;
+            __builtin_amdgcn_global_load_lds((glb_void *)p, (lds_void *)(dx + i * RPP * 128), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) rb[i] = *(const uint4 *)(wrow[i] + (size_t)kt * 64);
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(wrow[i] + (size_t)kt * 64), (lds_void *)(dw + i * RPP * 128), 16, 0, 0);
         kc += 64;
         while (kc >= a.Cin_pad) { kc -= a.Cin_pad; ++tap; }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            int r = r0 + i * RPP;
-            *(uint4 *)(sX + buf * (BP * 128) + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            int r = r0 + i * RPP;
-            *(uint4 *)(sW + buf * (BC * 128) + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
-        }
     };
 
     f32x4 acc[TC][TP];
@@ -125,14 +127,13 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = a.Kpad / 64;
-    load_global(0);
-    store_lds(0);
+    stage(0, 0);
     __syncthreads();
 
     const int l15 = lane & 15, lq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_global(kt + 1);
+        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
         const char *bx = sX + buf * (BP * 128) + (wpi * TP * 16 + l15) * 128;
         const char *bw = sW + buf * (BC * 128) + (wci * TC * 16 + l15) * 128;
 #pragma unroll
@@ -149,8 +150,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_lds(buf ^ 1);
-        __syncthreads();
+        __syncthreads();      // drains this step's global_load_lds (vmcnt(0)) and orders LDS reuse
     }
 
     // ---- epilogue: bias + activation (+ residual), 4 consecutive channels per lane ----
@@ -204,6 +204,8 @@ static const CfgDesc kCfgs[] = {
     {"p256c128_w4x2", 4, 2, 4, 4},
     {"p128c256_w2x4", 2, 4, 4, 4},
     {"p64c64_w2x2", 2, 2, 2, 2},
+    {"p256c256_w2x4", 2, 4, 8, 4},
+    {"p256c256_w4x2", 4, 2, 4, 8},
 };
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
 const char *conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) ? kCfgs[cfg].name : "?"; }
@@ -225,7 +227,7 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     const size_t lds = 2 * (size_t)(BP + BC) * 128;
-    dim3 grid((unsigned)tiles), block(64 * WP * WC);
+    dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * WP * WC);   // multiple of 8: see the XCD mapping
     if (a.out_f32) {
         auto k = conv_igemm_bf16<WP, WC, TP, TC, true>;
         if (lds > 65536) {
@@ -255,6 +257,8 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     case 5: return launch_t<4, 2, 4, 4>(a, s);
     case 6: return launch_t<2, 4, 4, 4>(a, s);
     case 7: return launch_t<2, 2, 2, 2>(a, s);
+    case 8: return launch_t<2, 4, 8, 4>(a, s);
+    case 9: return launch_t<4, 2, 4, 8>(a, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -121,34 +121,59 @@ def write_weights_file(path, flat, major=0, minor=2, revision=0, seen=0):
         np.asarray(flat, dtype=np.float32).tofile(f)
 
 
-def synth_weights(secs, seed=0, obj_bias=-4.0):
-    """Seeded synthetic parameter stream: W ~ N(0, 2/(k*k*Cin)) (darknet's own init,
-    DN/convolutional_layer.c:205-209), gamma ~ U(.8,1.2), beta ~ N(0,.1), mean ~ N(0,.1),
-    var ~ U(.5,1.5); head convs: W ~ N(0, 1/Cin), class/box biases N(0,1)/N(0,.5), objectness
-    bias `obj_bias` so a few % of candidates pass 0.5."""
+def synth_weights(secs, seed=0, obj_bias=-0.75):
+    """Seeded synthetic parameter stream, valid for any supported topology.
+
+    Filters W ~ N(0, 2/(k*k*Cin)) (darknet's own init, DN/convolutional_layer.c:205-209); gamma ~ U(.8,1.2),
+    beta ~ N(0,.1), rolling_mean ~ N(0,.1).  rolling_variance is set to the *expected* variance of the
+    conv output (tracked analytically through conv / shortcut / route), times U(.8,1.25) -- what a trained
+    network's statistics look like -- so activations stay O(1) through 75 layers instead of growing
+    ~1.1x per layer (the reference's real files span var 2e-3..16, D2T/log.txt).  Head convs: small
+    filters, class/box biases N(0,1)/N(0,.5), objectness bias `obj_bias` (a few % of candidates pass 0.5)."""
     rng = np.random.default_rng(seed)
     layers = secs[1:]
+    shapes = layer_shapes(secs)
+    m2 = []                  # expected second moment of each layer's output
+    cur = 1.0 / 3.0          # uniform [0,1) pixels: E[x^2]
     parts = []
-    for c in conv_specs(secs):
-        n, k, cin = c["filters"], c["size"], c["cin"]
-        if c["bn"]:
-            parts += [rng.normal(0, .1, n), rng.uniform(.8, 1.2, n), rng.normal(0, .1, n), rng.uniform(.5, 1.5, n)]
-            parts.append(rng.normal(0, np.sqrt(2.0 / (k * k * cin)), n * cin * k * k))
-        else:
-            b = rng.normal(0, 1.0, n)
-            if c["head"]:
-                h = layers[c["index"] + 1]
-                classes = int(h.get("classes", 20))
-                na = len(h["mask"].split(",")) if "mask" in h else int(h.get("num", 1))
-                attrs = 5 + classes
-                if na * attrs == n:
-                    b = b.reshape(na, attrs)
-                    b[:, 0:4] = rng.normal(0, .5, (na, 4))
-                    b[:, 4] = obj_bias + rng.normal(0, .5, na)
-                    b = b.reshape(-1)
-            parts.append(b)
-            # head pre-activations stay O(1) so exp(tw) cannot overflow on synthetic inputs
-            parts.append(rng.normal(0, 0.25 * np.sqrt(1.0 / (k * k * cin)), n * cin * k * k))
+    for i, s in enumerate(layers):
+        t = s["type"]
+        if t == "convolutional":
+            n, k, cin = int(s["filters"]), int(s["size"]), shapes[i][4]
+            head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
+            if int(s.get("batch_normalize", 0)):
+                pre_var = 2.0 * cur                                   # k*k*cin * (2/(k*k*cin)) * E[x^2]
+                gamma = rng.uniform(.8, 1.2, n)
+                parts += [rng.normal(0, .1, n), gamma, rng.normal(0, .1 * np.sqrt(pre_var), n), pre_var * rng.uniform(.8, 1.25, n)]
+                parts.append(rng.normal(0, np.sqrt(2.0 / (k * k * cin)), n * cin * k * k))
+                post = 1.0 + 0.01                                     # gamma^2 + beta^2 on average
+                cur = post * (0.505 if s.get("activation", "linear") == "leaky" else 1.0)
+            else:
+                b = rng.normal(0, 1.0, n)
+                if head:
+                    h = layers[i + 1]
+                    classes = int(h.get("classes", 20))
+                    na = len(h["mask"].split(",")) if "mask" in h else int(h.get("num", 1))
+                    attrs = 5 + classes
+                    if na * attrs == n:
+                        b = b.reshape(na, attrs)
+                        b[:, 0:4] = rng.normal(0, .5, (na, 4))
+                        b[:, 4] = obj_bias + rng.normal(0, .5, na)
+                        b = b.reshape(-1)
+                parts.append(b)
+                parts.append(rng.normal(0, np.sqrt(1.0 / (k * k * cin * max(cur, 1e-6))), n * cin * k * k))
+                cur = 1.0 + 1.0
+        elif t == "shortcut":
+            f = int(s["from"]); f = f if f >= 0 else i + f
+            # leaky outputs have a positive mean, so residual branches add coherently: use the fully
+            # correlated bound (slightly over-normalises, never explodes)
+            cur = (np.sqrt(m2[i - 1]) + np.sqrt(m2[f])) ** 2
+        elif t == "route":
+            ls = [int(x) for x in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            tot = sum(shapes[l][3] for l in ls)
+            cur = sum(m2[l] * shapes[l][3] for l in ls) / tot
+        m2.append(cur)
     return np.concatenate(parts).astype(np.float32)
 
 

@@ -1,0 +1,63 @@
+"""Multi-GPU data parallelism for the detect path: one process per GPU, images sharded by rank, ONE
+exchange step -- an all-gather of fixed-capacity detection records.
+
+The reference has no inference-time parallelism at all (single `tf.Session`, single device; its only
+multi-GPU code is host-mediated weight averaging for training, DN/network.c:857-1121), so there is no call
+pattern to mirror: each rank holds a full replica of the folded weights, runs conv stack + decode + NMS on
+its own images, and the ranks exchange `[B/G, max_out] x 24-byte records + [B/G] counts` (a few KB; latency
+bound).  `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+"""
+import numpy as np
+
+RECORD_FLOATS = 6        # x0, y0, x1, y1, score, class(as int32 bits)
+
+
+def shard_bounds(global_batch, world_size, rank):
+    """Contiguous split of the global batch; earlier ranks take the remainder."""
+    base, rem = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(boxes, counts, max_out):
+    """structured yolo_box array [n,max_out] + counts [n] -> one int32 buffer [n, 1 + max_out*6] (count first),
+    so a single collective moves both."""
+    n = boxes.shape[0]
+    buf = np.zeros((n, 1 + max_out * RECORD_FLOATS), dtype=np.int32)
+    buf[:, 0] = counts
+    buf[:, 1:] = boxes.view(np.int32).reshape(n, max_out * RECORD_FLOATS)
+    return buf
+
+
+def unpack_records(buf, box_dtype, max_out):
+    n = buf.shape[0]
+    counts = buf[:, 0].copy()
+    boxes = np.ascontiguousarray(buf[:, 1:]).view(box_dtype).reshape(n, max_out)
+    return [boxes[i, :counts[i]].copy() for i in range(n)]
+
+
+def all_gather_detections(local_buf, global_batch, group=None):
+    """local_buf: torch int32 tensor [n_local, 1 + max_out*6] on the rank's device (CPU for gloo).
+    Every rank contributes a block padded to ceil(B/G) rows (all_gather needs equal sizes); returns the
+    [global_batch, ...] tensor in global image order on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = -(-global_batch // world)
+    width = local_buf.shape[1]
+    padded = torch.zeros((per, width), dtype=local_buf.dtype, device=local_buf.device)
+    padded[:local_buf.shape[0]] = local_buf
+    out = torch.empty((world * per, width), dtype=local_buf.dtype, device=local_buf.device)
+    dist.all_gather_into_tensor(out, padded, group=group) if hasattr(dist, "all_gather_into_tensor") and local_buf.is_cuda \
+        else _all_gather_list(out, padded, world, per, group)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_bounds(global_batch, world, r)
+        rows.append(out[r * per:r * per + (hi - lo)])
+    return torch.cat(rows, dim=0)
+
+
+def _all_gather_list(out, padded, world, per, group):
+    import torch.distributed as dist
+    parts = [out[r * per:(r + 1) * per] for r in range(world)]
+    dist.all_gather(parts, padded, group=group)
