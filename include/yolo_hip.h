@@ -59,7 +59,11 @@ enum yolo_image_format {
 enum yolo_nms_mode {
     YOLO_NMS_TF = 0,           /* tf.image.non_max_suppression: class-agnostic, `>` iou, top max_out (row N1) */
     YOLO_NMS_PER_CLASS = 1,    /* V2 bboxes_nms (V2/utils.py:176-187): same-class, drop unless iou < thr (row N3) */
-    YOLO_NMS_DARKNET = 2       /* do_nms_sort (DN/box.c:58-89) on max-class score: same-class, drop if iou > thr */
+    YOLO_NMS_DARKNET = 2,      /* do_nms_sort (DN/box.c:58-89) on max-class score: same-class, drop if iou > thr */
+    YOLO_NMS_NUMPY_V3 = 3      /* `non_max_suppression` V3/yolo_v3.py:376-420 (row N2): gate on objectness > thr, class =
+                                * argmax cls, per class by objectness, keep iou < thr with the unclamped `_iou`; reported
+                                * score reproduces the reference's shifted-index behaviour.  Records come out class by
+                                * class (ascending), in selection order; boxes are corners (x - w/2 form). */
 };
 enum yolo_select_mode {
     YOLO_SELECT_GT = 0,        /* max(obj*cls) >  thr  (V3/YOLOV3.py:358) */
@@ -166,7 +170,8 @@ int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float *out, int d
 /* head decode of raw [n,g,g,na*(5+classes)] fp32: yolo (logistic) or region (softmax) */
 int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const float *anchors_wh,
                    int img_size, int decode, int region, float *out, int device);
-/* threshold + NMS over det [n,rows,attrs] fp32 */
+/* threshold + NMS over det [n,rows,attrs] fp32.  nms_mode bits 8..19 / 20..31 carry image height / width for
+ * YOLO_NMS_PER_CLASS (V2 pixel boxes); select_mode bit 8 set = rows already hold corners (x0,y0,x1,y1). */
 int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr,
                         int max_out, int nms_mode, int select_mode, yolo_box *boxes_out,
                         int32_t *counts_out, int device);

@@ -1,0 +1,97 @@
+"""The Python entry points that keep the reference's names/signatures, run on the device, against golden vectors
+captured from the reference's own numpy functions and against the oracle."""
+import numpy as np
+import pytest
+from conftest import golden
+from oracle import yolo_ref as R
+from yolo_tensorflow_amd import darknet_io as IO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_non_max_suppression_equals_reference_numpy(hiplib):
+    """`non_max_suppression` (V3/yolo_v3.py:376-420) on the device == the reference's own output, bit for bit,
+    including its shifted-score behaviour (golden captured by importing the reference)."""
+    from yolo_tensorflow_amd import yolo_v3
+    g = golden("nms_v3_numpy.npz")
+    res = yolo_v3.non_max_suppression(g["det"], float(g["conf"]), float(g["iou"]))
+    keys = sorted(res.keys())
+    assert keys == list(g["classes"])
+    assert [len(res[k]) for k in keys] == list(g["counts"])
+    boxes = np.concatenate([np.array([b for b, _ in res[k]], dtype=np.float32) for k in keys])
+    scores = np.concatenate([np.array([s for _, s in res[k]], dtype=np.float32) for k in keys])
+    assert np.array_equal(boxes, g["boxes"])
+    assert np.array_equal(scores, g["scores"])
+
+
+def test_non_max_suppression_vs_oracle_random(hiplib):
+    from yolo_tensorflow_amd import yolo_v3
+    rng = np.random.default_rng(31)
+    det = rng.uniform(0, 1, (2, 500, 5 + 12)).astype(np.float32)
+    det[..., 2:4] = det[..., 0:2] + rng.uniform(0.05, 0.4, (2, 500, 2)).astype(np.float32)
+    det[..., 4] = rng.uniform(0, 1, (2, 500)) ** 3
+    want = R.np_nms_v3(det, 0.3, 0.4)
+    got = yolo_v3.non_max_suppression(det, 0.3, 0.4)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert len(got[k]) == len(want[k])
+        for (gb, gs), (wb, ws) in zip(got[k], want[k]):
+            assert np.array_equal(gb, wb) and gs == ws
+    assert yolo_v3.non_max_suppression(det, 2.0, 0.4) == {}
+
+
+def test_v2_postprocess_equals_reference_numpy(hiplib):
+    """V2 `postprocess` (V2/utils.py:30-62) on the device == the reference's own output (golden), bit for bit."""
+    from yolo_tensorflow_amd import yolo_v2
+    g = golden("v2_postprocess.npz")
+    b, s, c = yolo_v2.postprocess(g["bboxes"], g["obj"], g["cls"], image_shape=tuple(int(v) for v in g["image_shape"]), threshold=float(g["threshold"]))
+    assert np.array_equal(b, g["out_boxes"]) and np.array_equal(s, g["out_scores"]) and np.array_equal(c, g["out_classes"])
+
+
+def test_yolo_v3_entry_points(hiplib, tmp_path):
+    from yolo_tensorflow_amd import yolo_v3
+    size = 96
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 0)
+    wf = str(tmp_path / "yolov3.weights"); IO.write_weights_file(wf, flat, 0, 2)
+    yolo_v3.load_weights(None, wf, size=size, max_batch=2, dtype=hiplib.FP32)
+    rng = np.random.default_rng(3)
+    inputs = rng.integers(0, 256, (2, size, size, 3)).astype(np.float32)       # the reference feeds float32 0..255
+    det = yolo_v3.yolo_v3(inputs, 80, data_format='NHWC')
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    heads, _ = R.forward(osecs, params, inputs / np.float32(255))
+    ref = R.yolo_v3_detections(heads, size, ratio=False)                      # pixel units (V3/yolo_v3.py:111-159)
+    assert det.shape == ref.shape == (2, 9 * 3 + 36 * 3 + 144 * 3, 85)
+    np.testing.assert_allclose(det, ref, rtol=2e-3, atol=2e-3)
+    boxes = yolo_v3.detections_boxes(det)
+    assert np.array_equal(boxes, R.detections_boxes(det))
+    # 4-output variant: normalised detections + per-image TF NMS
+    d2, bb, ss, cc = yolo_v3.yolo_v3_with_nms(inputs, 80, score_threshold=0.3, iou_threshold=0.5, data_format='NHWC')
+    np.testing.assert_allclose(d2[..., :4] * size, det[..., :4], rtol=1e-4, atol=1e-3)
+    for b in range(2):
+        wb, ws, wc = R.detect_v3_tf(d2[b], 0.3, 0.5, 20)
+        assert np.array_equal(bb[b], wb) and np.array_equal(ss[b], ws) and np.array_equal(cc[b], wc)
+    with pytest.raises(hiplib.YoloError):
+        yolo_v3.yolo_v3(np.zeros((1, 64, 64, 3), np.float32), 80)            # nothing bound at that size
+    for m in list(yolo_v3._default.values()):
+        m.close()
+    yolo_v3._default.clear()
+
+
+def test_detector_classes(hiplib):
+    """YOLOV3 / YOLOV2 converter-class counterparts: uint8 image of any size in, (scores, boxes, classes) out."""
+    from yolo_tensorflow_amd import detector
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    for cls, name in ((detector.YOLOV3Tiny, "yolov3-tiny"), (detector.YOLOV2TinyVoc, "yolov2-tiny-voc")):
+        flat = IO.synth_weights(IO.parse_cfg(IO.cfg_text(name)), 0)
+        d = cls(None, weights=flat, dtype=hiplib.FP32)
+        scores, boxes, classes = d.detect_from_image(img)
+        assert len(scores) == len(boxes) == len(classes) <= d.max_output_size
+        # same tail from the oracle on the device's decoded tensor of the oracle-resized image
+        det = d.engine.forward(np.ascontiguousarray(R.input_process(img, 416)), scale=1.0)[0]
+        if "v3" in name:
+            wb, ws, wc = R.detect_v3_tf(det, d.threshold, d.iou_threshold, d.max_output_size)
+            assert len(ws) == len(scores)
+            np.testing.assert_allclose(scores, ws, rtol=1e-3, atol=1e-4)
+        d.engine.close()

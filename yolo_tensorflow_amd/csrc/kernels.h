@@ -63,11 +63,14 @@ struct DecodeArgs {
     int region;                         // 1: softmax/region head
     float *det; int rows_total; int row_off;   // det [n, rows_total, 5+classes]
 };
-hipError_t launch_decode(const DecodeArgs &a, hipStream_t s);
+// scores/labels (nullable): per-row max_k(obj*cls_k) and its first argmax, written alongside the decode
+hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s);
 
 struct PostArgs {
     const float *det; int n, rows, attrs;
     float score_thr, iou_thr; int max_out, nms_mode, select_mode;
+    int scores_ready;                   // 1: scores/labels were produced by the decode kernel already
+    int corners_in;                     // 1: det rows already hold (x0,y0,x1,y1) instead of (cx,cy,w,h)
     int img_h, img_w;                   // V2 numpy flavour only: pixel box scaling (V2/utils.py:32-43); 0 = off
     // workspace (device), sized for n images: scores/labels/cand/slabel/sscore [n*rows], sbox float4 [n*rows],
     // keys u64 [n*rows_pow2]

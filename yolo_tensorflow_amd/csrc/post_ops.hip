@@ -15,31 +15,66 @@
 struct BoxOut { float x0, y0, x1, y1, score; int cls; };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+void launch_score_rows(const float *det, size_t nrows, int attrs, float *scores, int *labels, hipStream_t s, int objectness_mode = 0);
 
-// ---- D3: `_detection_layer` (V3/yolo_v3.py:111-159) / `_ratio_detection_layer` (V3/YOLOV3.py:168-238) ----
-__global__ void k_decode_yolo(const DecodeArgs a)
+// wave-wide (value, first index) arg-max over lanes; every lane returns the result
+__device__ __forceinline__ void wave_argmax(float &v, int &idx)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ov = __shfl_xor(v, off);
+        int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// ---- D3 (+S): `_detection_layer` (V3/yolo_v3.py:111-159) / `_ratio_detection_layer` (V3/YOLOV3.py:168-238),
+//      fused with the row score of V3/YOLOV3.py:353-357.  One wave per candidate box: lanes run along the
+//      5+C attributes (contiguous in the head tensor and in the decoded tensor -> fully coalesced), the
+//      max/argmax over classes is a wave shuffle reduction. ----
+__global__ __launch_bounds__(256) void k_decode_yolo(const DecodeArgs a, float *scores, int *labels)
 {
     const int attrs = 5 + a.classes;
-    const size_t total = (size_t)a.n * a.g * a.g * a.na * attrs;
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    int attr = (int)(idx % attrs); size_t box = idx / attrs;
-    int an = (int)(box % a.na); size_t t = box / a.na;
-    int cell = (int)(t % (a.g * a.g)); int b = (int)(t / (a.g * a.g));
-    float v = a.raw[((size_t)b * a.g * a.g + cell) * a.raw_stride + an * attrs + attr];
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const long total = (long)a.n * a.g * a.g * a.na;
     const int stride = a.img_size / a.g;
-    float r;
-    if (attr < 2) {
-        float off = (float)(attr == 0 ? cell % a.g : cell / a.g);
-        float s = sigmoidf_(v) + off;
-        r = a.mode == 0 ? s / (float)a.g : s * (float)stride;
-    } else if (attr < 4) {
-        float e = expf(v) * a.anchors[2 * an + (attr - 2)];       // anchors pre-divided by stride on the host
-        r = a.mode == 0 ? e / (float)a.g : e * (float)stride;
-    } else {
-        r = sigmoidf_(v);
+    const float G = (float)a.g, S = (float)stride;
+    for (long box = wave; box < total; box += nwaves) {
+        const int an = (int)(box % a.na); const long t = box / a.na;
+        const int cell = (int)(t % (a.g * a.g)); const int b = (int)(t / (a.g * a.g));
+        const float *p = a.raw + ((size_t)b * a.g * a.g + cell) * a.raw_stride + an * attrs;
+        const size_t row = (size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na + an;
+        float *o = a.det + row * attrs;
+        float best = -INFINITY; int bi = 0x7fffffff;
+        float obj = 0.f;
+        for (int base = 0; base < attrs; base += 64) {
+            const int attr = base + lane;
+            float r = 0.f;
+            if (attr < attrs) {
+                const float v = p[attr];
+                if (attr < 2) {
+                    const float off = (float)(attr == 0 ? cell % a.g : cell / a.g);
+                    const float sg = sigmoidf_(v) + off;
+                    r = a.mode == 0 ? sg / G : sg * S;
+                } else if (attr < 4) {
+                    const float e = expf(v) * a.anchors[2 * an + (attr - 2)];   // anchors pre-divided by stride on the host
+                    r = a.mode == 0 ? e / G : e * S;
+                } else {
+                    r = sigmoidf_(v);
+                }
+                o[attr] = r;
+            }
+            if (base == 0) obj = __shfl(r, 4);
+            if (attr >= 5 && attr < attrs) {
+                const float sc = obj * r;
+                if (sc > best) { best = sc; bi = attr - 5; }
+            }
+        }
+        wave_argmax(best, bi);
+        if (lane == 0 && scores) { scores[row] = best; labels[row] = bi; }
     }
-    a.det[((size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na + an) * attrs + attr] = r;
 }
 
 // ---- D2: V2 `decode` (V2/decode.py:13-47): sigmoid xy/obj, exp wh, softmax classes; stored as
@@ -67,31 +102,50 @@ __global__ void k_decode_region(const DecodeArgs a)
     for (int k = 0; k < a.classes; ++k) o[5 + k] = expf(p[5 + k] - mx) / sum;
 }
 
-hipError_t launch_decode(const DecodeArgs &a, hipStream_t s)
+hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s)
 {
     if (a.region) {
         size_t total = (size_t)a.n * a.g * a.g * a.na;
         hipLaunchKernelGGL(k_decode_region, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, a);
+        if (scores) {
+            // region heads are tiny (845 rows/image): score them with the generic row kernel
+            const size_t rows = (size_t)a.g * a.g * a.na;
+            for (int b = 0; b < a.n; ++b)
+                launch_score_rows(a.det + ((size_t)b * a.rows_total + a.row_off) * (5 + a.classes), rows, 5 + a.classes,
+                                  scores + (size_t)b * a.rows_total + a.row_off, labels + (size_t)b * a.rows_total + a.row_off, s);
+        }
     } else {
-        size_t total = (size_t)a.n * a.g * a.g * a.na * (5 + a.classes);
-        hipLaunchKernelGGL(k_decode_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        size_t total = (size_t)a.n * a.g * a.g * a.na;             // one wave per box, grid-stride
+        size_t blocks = (total + 3) / 4; if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_decode_yolo, dim3((unsigned)blocks), dim3(256), 0, s, a, scores, labels);
     }
     return hipGetLastError();
 }
 
-// ---- S: box_scores = confidence * class_prob; argmax / reduce_max (V3/YOLOV3.py:353-357) ----
-__global__ void k_score_rows(const float *det, size_t nrows, int attrs, float *scores, int *labels)
+// ---- S: box_scores = confidence * class_prob; argmax / reduce_max (V3/YOLOV3.py:353-357).  One wave per row,
+//      lanes along the attributes (coalesced), shuffle arg-max (first maximum, like argmax). ----
+__global__ __launch_bounds__(256) void k_score_rows(const float *det, size_t nrows, int attrs, float *scores, int *labels, int objectness_mode)
 {
-    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    const float *p = det + r * attrs;
-    const float obj = p[4];
-    float best = -INFINITY; int bi = 0;
-    for (int k = 0; k < attrs - 5; ++k) {
-        float s = obj * p[5 + k];
-        if (s > best) { best = s; bi = k; }         // first maximum, like argmax
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < nrows; r += nwaves) {
+        const float *p = det + r * attrs;
+        const float obj = p[4];
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int k = lane; k < attrs - 5; k += 64) {
+            // objectness_mode (V3/yolo_v3.py:385,397): gate on obj alone, class = argmax of the raw class scores
+            float sc = objectness_mode ? p[5 + k] : obj * p[5 + k];
+            if (sc > best) { best = sc; bi = k; }
+        }
+        wave_argmax(best, bi);
+        if (lane == 0) { scores[r] = objectness_mode ? obj : best; labels[r] = bi; }
     }
-    scores[r] = best; labels[r] = bi;
+}
+void launch_score_rows(const float *det, size_t nrows, int attrs, float *scores, int *labels, hipStream_t s, int objectness_mode)
+{
+    size_t blocks = (nrows + 3) / 4; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_score_rows, dim3((unsigned)blocks), dim3(256), 0, s, det, nrows, attrs, scores, labels, objectness_mode);
 }
 
 // TF NonMaxSuppression IOU on [y0,x0,y1,x1] rows (min/max-normalised corners, 0 when an area <= 0)
@@ -131,6 +185,15 @@ __device__ __forceinline__ float iou_darknet(float4 a, float4 b)
     float inter = (w < 0 || h < 0) ? 0.f : w * h;
     float uni = a.z * a.w + b.z * b.w - inter;
     return inter / uni;
+}
+
+// `_iou` of the reference's numpy NMS (V3/yolo_v3.py:350-373): float32, NO clamp of a negative overlap, +1e-05
+__device__ __forceinline__ float iou_numpy_v3(float4 a, float4 b)
+{
+    float ix0 = fmaxf(a.x, b.x), iy0 = fmaxf(a.y, b.y), ix1 = fminf(a.z, b.z), iy1 = fminf(a.w, b.w);
+    float inter = (ix1 - ix0) * (iy1 - iy0);
+    float a1 = (a.z - a.x) * (a.w - a.y), a2 = (b.z - b.x) * (b.w - b.y);
+    return inter / (a1 + a2 - inter + 1e-05f);
 }
 
 #define NMS_THREADS 1024
@@ -184,6 +247,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
             unsigned int u = __float_as_uint(scores[cand[i]]);
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone map of float order
             k = ((unsigned long long)(~u) << 32) | (unsigned int)i;
+            if (a.nms_mode == 3)       // per class (ascending), then objectness descending, then candidate index
+                k = ((unsigned long long)(labels[cand[i]] & 0x3ff) << 47) | ((unsigned long long)(~u) << 15) | (unsigned int)(i & 0x7fff);
         }
         keys[i] = k;
     }
@@ -204,10 +269,10 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     if (a.nms_mode == 1 && M > 400) M = 400;
     // (4) gather candidates in sorted order
     for (int i = tid; i < M; i += NMS_THREADS) {
-        int row = cand[(unsigned int)(keys[i] & 0xffffffffu)];
+        int row = cand[(unsigned int)(keys[i] & (a.nms_mode == 3 ? 0x7fffu : 0xffffffffu))];
         const float *p = a.det + ((size_t)img * a.rows + row) * a.attrs;
         float4 b;
-        if (a.nms_mode == 2) b = float4{p[0], p[1], p[2], p[3]};                       // (cx,cy,w,h)
+        if (a.nms_mode == 2 || a.corners_in) b = float4{p[0], p[1], p[2], p[3]};       // (cx,cy,w,h) for darknet; given corners
         else {
             float w2 = p[2] * 0.5f, h2 = p[3] * 0.5f;                                      // V3/YOLOV3.py:348-351
             b = float4{p[0] - w2, p[1] - h2, p[0] + w2, p[1] + h2};
@@ -229,6 +294,66 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     }
     if (tid == 0) { s_cur = -1; s_kept = 0; }
     __syncthreads();
+
+    if (a.nms_mode == 3) {
+        // Reference numpy NMS (V3/yolo_v3.py:376-420), class by class over the sorted list.  The reference filters
+        // `cls_scores` with indices taken on `cls_boxes[1:]` (:414-418), so after every round each survivor
+        // inherits the score of the element that preceded it in the current list -- reproduced here.
+        __syncthreads();
+        int *list = cand;                               // compacted alive positions (cand is free after the gather)
+        float *tmp = (float *)gkeys;                    // scratch for the shifted scores (keys are free as well)
+        __shared__ int s_seg_end;
+        int seg = 0;
+        while (seg < M) {
+            if (tid == 0) { int e = seg + 1; const int lc = slabel[seg]; while (e < M && slabel[e] == lc) ++e; s_seg_end = e; }
+            __syncthreads();
+            const int seg_end = s_seg_end;
+            while (true) {
+                // compact the alive positions of this class segment, in order
+                if (tid == 0) s_base = 0;
+                __syncthreads();
+                for (int r0 = seg; r0 < seg_end; r0 += NMS_THREADS) {
+                    int j = r0 + tid;
+                    bool f = j < seg_end && ((alive[j >> 5] >> (j & 31)) & 1u);
+                    unsigned long long m = __ballot(f);
+                    if (lane == 0) wave_cnt[wv] = __popcll(m);
+                    __syncthreads();
+                    int pre = 0, tot = 0;
+                    for (int i = 0; i < NMS_THREADS / 64; ++i) { int c = wave_cnt[i]; if (i < wv) pre += c; tot += c; }
+                    int base = s_base;
+                    if (f) list[base + pre + __popcll(m & ((1ull << lane) - 1))] = j;
+                    __syncthreads();
+                    if (tid == 0) s_base = base + tot;
+                    __syncthreads();
+                }
+                const int len = s_base;
+                if (len == 0) break;
+                const int head = list[0];
+                const float4 bh = sbox[head];
+                const int kept = s_kept;
+                if (tid == 0) {
+                    if (kept < a.max_out) out[kept] = BoxOut{bh.x, bh.y, bh.z, bh.w, sscore[head], slabel[head]};
+                    s_kept = kept + 1;
+                    atomicAnd(&alive[head >> 5], ~(1u << (head & 31)));
+                }
+                for (int m2 = 1 + tid; m2 < len; m2 += NMS_THREADS) {
+                    const int j = list[m2];
+                    if (iou_numpy_v3(bh, sbox[j]) < a.iou_thr) tmp[j] = sscore[list[m2 - 1]];     // survivor: shifted score
+                    else atomicAnd(&alive[j >> 5], ~(1u << (j & 31)));
+                }
+                __syncthreads();
+                for (int m2 = 1 + tid; m2 < len; m2 += NMS_THREADS) {
+                    const int j = list[m2];
+                    if ((alive[j >> 5] >> (j & 31)) & 1u) sscore[j] = tmp[j];
+                }
+                __syncthreads();
+            }
+            seg = seg_end;
+            __syncthreads();
+        }
+        if (tid == 0) a.counts_out[img] = min(s_kept, a.max_out);
+        return;
+    }
 
     // (5) greedy: the best alive candidate is kept and suppresses every later one it overlaps
     int pos = 0;
@@ -272,7 +397,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s)
 {
     size_t nrows = (size_t)a.n * a.rows;
-    hipLaunchKernelGGL(k_score_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, a.det, nrows, a.attrs, a.scores, a.labels);
+    if (!a.scores_ready) launch_score_rows(a.det, nrows, a.attrs, a.scores, a.labels, s, a.nms_mode == 3);
     hipLaunchKernelGGL(k_nms_image, dim3(a.n), dim3(NMS_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -75,6 +75,7 @@ struct yolo_ctx {
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
     void *d_boxes = nullptr; int *d_counts = nullptr; int boxes_cap = 0;
     bool weights_loaded = false;
+    int scores_mode = -1;                 // what d_scores/d_labels hold: 0 max(obj*cls) from the decode, 1 objectness, -1 nothing
     size_t weights_count = 0;
     double conv_flops = 0;
     int last_n = 0;
@@ -395,7 +396,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         for (int k = 0; k < 2 * L.na; ++k)
             d.anchors[k] = L.type == L_YOLO ? (float)(1.0 * (double)L.anchors[k] / (double)stride) : L.anchors[k];
         d.det = c->d_det; d.rows_total = c->rows; d.row_off = L.row_off;
-        HIPCK(c, launch_decode(d, s));
+        HIPCK(c, launch_decode(d, c->d_scores, c->d_labels, s));
         break; }
     }
     return YOLO_OK;
@@ -418,7 +419,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
 int run_network(yolo_ctx *c, int n)
 {
     for (int i = 0; i < (int)c->layers.size(); ++i) { int r = run_layer(c, i, n); if (r) return r; }
-    c->last_n = n;
+    c->last_n = n; c->scores_mode = 0;
     return YOLO_OK;
 }
 
@@ -430,10 +431,10 @@ int copy_out(yolo_ctx *c, void *dst, const void *src, size_t bytes, int loc)
 }
 
 int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out,
-         int nms_mode, int select_mode, int img_h, int img_w, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+         int nms_mode, int select_mode, int img_h, int img_w, int scores_ready, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
 {
     if (max_out < 1) return fail(c, YOLO_ERR_INVALID, "max_out < 1");
-    if (nms_mode < 0 || nms_mode > 2 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
+    if (nms_mode < 0 || nms_mode > 3 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
     size_t need = (size_t)n * max_out;
     if ((int)need > c->boxes_cap) {
         if (c->d_boxes) HIPCK(c, hipFree(c->d_boxes));
@@ -441,7 +442,7 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
     }
     PostArgs p; memset(&p, 0, sizeof p);
     p.det = det; p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_out;
-    p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w;
+    p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w; p.scores_ready = scores_ready;
     p.scores = c->d_scores; p.labels = c->d_labels; p.cand = c->d_cand; p.keys = c->d_keys; p.rows_pow2 = c->rows_pow2;
     p.sbox = c->d_sbox; p.slabel = c->d_slabel; p.sscore = c->d_sscore; p.boxes_out = c->d_boxes; p.counts_out = c->d_counts;
     HIPCK(c, hipMemsetAsync(c->d_boxes, 0, need * sizeof(yolo_box), c->stream));
@@ -627,8 +628,11 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
     if (!c) return YOLO_ERR_INVALID;
     if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "postprocess of %d images but the last forward ran %d", n, c->last_n);
     HIPCK(c, hipSetDevice(c->device));
+    const int want = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
+    const int ready = c->scores_mode == want;
+    c->scores_mode = want;
     return post(c, c->d_det, n, c->rows, c->attrs, score_thr, iou_thr, max_out, nms_mode, select_mode,
-                nms_mode == YOLO_NMS_PER_CLASS ? c->in_h : 0, nms_mode == YOLO_NMS_PER_CLASS ? c->in_w : 0, boxes_out, counts_out, out_loc);
+                nms_mode == YOLO_NMS_PER_CLASS ? c->in_h : 0, nms_mode == YOLO_NMS_PER_CLASS ? c->in_w : 0, ready, boxes_out, counts_out, out_loc);
 }
 
 int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float score_thr, float iou_thr,
@@ -741,6 +745,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int r = 0; r < iters; ++r) launch_conv_bf16(a, cfg, c->stream);
             HIPCK(c, hipEventRecord(e1, c->stream)); HIPCK(c, hipEventSynchronize(e1));
             float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1));
+            if (getenv("YOLO_TUNE_VERBOSE")) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms\n", key, cfg, conv_cfg_name(cfg), ms / iters);
             if (ms < best) { best = ms; best_cfg = cfg; }
         }
         L.tile_cfg = best_cfg; memo[key] = best_cfg;
@@ -842,7 +847,7 @@ int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const fl
     const int stride = img_size / g;
     for (int k = 0; k < 2 * na; ++k) d.anchors[k] = region ? anchors_wh[k] : (float)(1.0 * (double)anchors_wh[k] / (double)stride);
     d.det = d_o; d.rows_total = g * g * na; d.row_off = 0;
-    if (!S.ok(launch_decode(d, S.s))) { g_op_err = S.err; return S.rc; }
+    if (!S.ok(launch_decode(d, nullptr, nullptr, S.s))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, cnt * 4);
 }
 
@@ -854,7 +859,7 @@ int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float scor
     size_t nr = (size_t)n * rows; int p2 = 1; while (p2 < rows) p2 <<= 1;
     PostArgs p; memset(&p, 0, sizeof p);
     p.det = (const float *)S.upload(det, nr * attrs * 4); p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr;
-    p.max_out = max_out; p.nms_mode = nms_mode & 0xff; p.select_mode = select_mode;
+    p.max_out = max_out; p.nms_mode = nms_mode & 0xff; p.select_mode = select_mode & 0xff; p.corners_in = (select_mode >> 8) & 1;
     // bits 8.. of nms_mode carry the image size for the V2 numpy flavour: (h << 8) | (w << 20)
     p.img_h = (nms_mode >> 8) & 0xfff; p.img_w = (nms_mode >> 20) & 0xfff;
     p.scores = (float *)S.alloc(nr * 4); p.labels = (int *)S.alloc(nr * 4); p.cand = (int *)S.alloc(nr * 4);

@@ -17,7 +17,7 @@ SEM_TF, SEM_DARKNET = 0, 1
 DECODE_RATIO, DECODE_PIXEL = 0, 1
 HOST, DEVICE = 0, 1
 IMG_U8, IMG_F32 = 0, 1
-NMS_TF, NMS_PER_CLASS, NMS_DARKNET = 0, 1, 2
+NMS_TF, NMS_PER_CLASS, NMS_DARKNET, NMS_NUMPY_V3 = 0, 1, 2, 3
 SELECT_GT, SELECT_GE = 0, 1
 
 BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("score", "<f4"), ("cls", "<i4")])
@@ -296,9 +296,12 @@ def op_decode(raw, anchors, classes, img_size, decode=DECODE_RATIO, region=False
     return out
 
 
-def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mode=SELECT_GT, image_hw=None, device=0):
+def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mode=SELECT_GT, image_hw=None, corners=False, device=0):
+    """det [n,rows,5+C] fp32 rows (cx,cy,w,h,obj,cls..) -- or (x0,y0,x1,y1,obj,cls..) with corners=True."""
     det = _f32(det); n, rows, attrs = det.shape
     mode = nms_mode
+    if corners:
+        select_mode |= 0x100
     if image_hw is not None:
         mode |= (int(image_hw[0]) << 8) | (int(image_hw[1]) << 20)
     boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)

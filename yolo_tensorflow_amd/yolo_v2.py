@@ -1,0 +1,74 @@
+"""Counterpart of the reference's YOLOv2 modules: `model_darknet19_slim.build_network`, `postprocess.decode` /
+`decode.decode`, `utils.preprocess_image` / `utils.postprocess`, `config.anchors` (V2/*.py).  Same names and
+argument meaning; the darknet-19 graph, the region decode and both NMS flavours run in libyolo_hip.so."""
+import numpy as np
+from . import hip, darknet_io as IO
+
+anchors = [[0.57273, 0.677385], [1.87446, 2.06253], [3.33843, 5.47434], [7.88282, 3.52778], [9.77052, 9.16828]]  # V2/config.py:7-11
+
+
+class Model:
+    def __init__(self, cfg="yolov2", size=416, max_batch=1, dtype=hip.FP32, device=0, weights_file=None, weights=None, semantics=hip.SEM_TF):
+        text = IO.cfg_text(cfg)
+        if size != int(IO.parse_cfg(text)[0]["width"]):
+            text = IO.with_input_size(text, size)
+        self.cfg_text, self.size = text, size
+        self.engine = hip.Engine(text, max_batch=max_batch, dtype=dtype, semantics=semantics, device=device)
+        if weights_file is not None:
+            self.engine.load_weights(weights_file)
+        elif weights is not None:
+            self.engine.set_weights(weights)
+
+    def close(self):
+        self.engine.close()
+
+
+def preprocess_image(image, image_size=(416, 416)):
+    """V2/utils.py:13-27 minus OpenCV: expects an RGB uint8 image, stretches it with the legacy bilinear rule on the
+    device and returns [1,H,W,3] float32.  NB the reference divides by 225.0 (a typo, :22); reproduced."""
+    if image_size[0] != image_size[1]:
+        raise hip.YoloError("square network input only")
+    x = hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0])      # value/255 then resize
+    return (x * np.float32(255.0 / 225.0))[None]
+
+
+def build_network(images, num_outputs=425, alpha=0.1, keep_prob=0.5, is_training=False, scope='yolov2', model=None):
+    """V2/model_darknet19_slim.py:119: images [N,416,416,3] already normalised -> the decoded head.  The reference
+    returns the raw [N,13,13,425] tensor and decodes in a second graph; the device fuses both, so this returns the
+    decoded rows [N, 845, 85] = (bx, by, bw, bh, objectness, softmax classes) that `decode` consumes."""
+    if model is None:
+        raise hip.YoloError("pass model=yolo_v2.Model(weights_file=...)")
+    return model.engine.forward(np.ascontiguousarray(images, dtype=np.float32), scale=1.0)
+
+
+def decode(model_output, output_sizes=(13, 13), num_class=80, threshold=None, iou_threshold=0.5, anchors=None, model=None):
+    """Two reference functions share this name:
+       V2/decode.py:13      decode(model_output, output_sizes, num_class, anchors) -> (bboxes, obj_probs, class_probs)
+       V2/postprocess.py:10 decode(..., threshold=0.5, iou_threshold=0.5, anchors) -> (boxes, scores, classes) after TF NMS (max 10)
+    `model_output` is what build_network returned.  threshold=None selects the first form."""
+    d = np.asarray(model_output, dtype=np.float32)
+    n = d.shape[0]
+    H, W = output_sizes
+    A = d.shape[1] // (H * W)
+    d4 = d.reshape(n, H * W, A, 5 + num_class)
+    two = np.float32(2)
+    bboxes = np.stack([d4[..., 0] - d4[..., 2] / two, d4[..., 1] - d4[..., 3] / two,
+                       d4[..., 0] + d4[..., 2] / two, d4[..., 1] + d4[..., 3] / two], axis=3)
+    if threshold is None:
+        return bboxes, d4[..., 4], d4[..., 5:]
+    res = hip.op_postprocess(d, threshold, iou_threshold, 10, hip.NMS_TF, hip.SELECT_GE)
+    r = res[0] if n == 1 else res
+    if n == 1:
+        return np.stack([r["x0"], r["y0"], r["x1"], r["y1"]], -1).reshape(-1, 4), r["score"], r["cls"]
+    return [np.stack([q["x0"], q["y0"], q["x1"], q["y1"]], -1).reshape(-1, 4) for q in r], [q["score"] for q in r], [q["cls"] for q in r]
+
+
+def postprocess(bboxes, obj_probs, class_probs, image_shape=(416, 416), threshold=0.5):
+    """V2/utils.py:30-62 on the device: scale to the image, int32 cast, clip, score = obj * max class, > threshold,
+    top-400, class-aware NMS (0.5).  Inputs as returned by the 3-output `decode`.  -> (bboxes int32, scores, classes)."""
+    b = np.asarray(bboxes, dtype=np.float32).reshape(-1, 4)
+    o = np.asarray(obj_probs, dtype=np.float32).reshape(-1)
+    c = np.asarray(class_probs, dtype=np.float32).reshape(len(o), -1)
+    det = np.concatenate([b, o[:, None], c], axis=1)[None]
+    r = hip.op_postprocess(det, threshold, 0.5, 400, hip.NMS_PER_CLASS, hip.SELECT_GT, image_hw=image_shape, corners=True)[0]
+    return np.stack([r["x0"], r["y0"], r["x1"], r["y1"]], -1).reshape(-1, 4).astype(np.int32), r["score"], r["cls"].astype(np.int64)
