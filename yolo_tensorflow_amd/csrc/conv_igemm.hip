@@ -13,14 +13,20 @@
 //     (bf16) or 16-byte (fp32) contiguous NHWC store.
 //   * K is walked in 64-wide steps; both operand tiles are staged in LDS as [rows][64] bf16 (128-B rows),
 //     16-B chunk index XOR-swizzled with (row & 7) so the ds_read_b128 fragment reads are conflict free.
-//   * Activation rows are gathered straight from the NHWC tensor (no im2col buffer): each 16-B chunk of
-//     a K-step is one (tap, 8-channel) slice of one input pixel; padding taps read a zero line.
-//   * Double-buffered LDS, global loads for step t+1 are issued before the MFMAs of step t and written
-//     to LDS after them (one barrier per K-step).
+//     LDS-DMA destinations are lane-linear, so the swizzle is applied to the SOURCE offset and to the read.
+//   * Activation rows are gathered straight from the NHWC tensor (no im2col buffer) with
+//     `buffer_load_dwordx4 ... offen lds`: per lane a CONSTANT 32-bit byte offset (its pixel, its 16-B chunk),
+//     per K-step one SCALAR offset (tap and channel base) -- the address arithmetic of a K-step is a handful of
+//     SALU instructions, not ~20 VALU per load (which had made the loop VALU-bound).  Padding taps and rows
+//     past the last pixel use an out-of-range offset: the buffer range check makes the DMA write zeros
+//     (verified on MI355X by tools/probe/lds_dma_oob.hip).
+//   * NS-stage LDS ring: the loads of K-step t+NS-1 are issued before the MFMAs of step t; a counted
+//     s_waitcnt vmcnt + one raw s_barrier per K-step keep them in flight across the barrier.
 #include "kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
 {
@@ -29,23 +35,31 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int WP, int WC, int TP, int TC, bool OUT_F32>
+#define OOB_OFFSET 0x80000000u                  // >= num_records of every descriptor below -> DMA writes zeros
+#define BUF_RECORDS 0x80000000u
+
+// UNI: Cin_pad is a multiple of 64, so all 8 chunks of a K-step belong to one tap (scalar tap cursor).
+// otherwise (Cin_pad = 8, 16, 32, ...): the chunks of one K-step span several taps, tap cursor is per lane.
+template <int WP, int WC, int TP, int TC, int NS, bool UNI>
 __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a)
 {
-    constexpr int NT = 64 * WP * WC;
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
+                                      // kernel whose body uses the buffer-resource builtins with array operands)
+    constexpr int NW = WP * WC;
     constexpr int BP = WP * TP * 16;           // output pixels per workgroup
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
-    constexpr int RPP = NT / 8;                // tile rows covered by one pass of 16-B loads
-    constexpr int LA = BP / RPP;
-    constexpr int LB = BC / RPP;
-    static_assert(BP % RPP == 0 && BC % RPP == 0, "tile/threads mismatch");
+    constexpr int GP = BP / 8, GC = BC / 8;    // 8-row groups (one wave-level LDS-DMA instruction each)
+    // every wave issues the same number of LDS-DMA instructions per K-step (the counted vmcnt relies on it): group
+    // counts are padded up to a multiple of the wave count; padded rows get an out-of-range offset (zeros, no traffic)
+    constexpr int LA = (GP + NW - 1) / NW, LB = (GC + NW - 1) / NW;
+    constexpr int L = LA + LB;
+    constexpr int BPL = LA * NW * 8, BCL = LB * NW * 8;      // rows of the LDS images
+    constexpr int STAGE_BYTES = (BPL + BCL) * 128;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sX = smem;                           // [2][BP][128 B]
-    char *sW = smem + 2 * BP * 128;            // [2][BC][128 B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][ BP rows | BC rows ][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,60 +78,99 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     const int ct = tile % tilesC;
     const int pt = tile / tilesC;
 
-    const bf16_t *__restrict__ in = (const bf16_t *)a.in;
-    const bf16_t *__restrict__ wt = (const bf16_t *)a.wt;
+    // Buffer descriptors.  The activation base is moved back by (W+1) pixels so that the offset of tap (0,0) of a
+    // border pixel (one row up, one column left) is still >= 0.
+    const int shift = (a.W + 1) * a.in_stride;                       // elements
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const bf16_t *)a.in - shift), 0, BUF_RECORDS, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.wt, 0, BUF_RECORDS, 0x00020000);
 
-    // ---- per-thread staging geometry: this thread always fetches LDS slot (row r0 + i*RPP, physical
-    //      chunk tid&7), i.e. logical K-chunk (tid&7) ^ (row&7) of that row (rule: swizzle the SOURCE) ----
-    const int r0 = tid >> 3;
-    const int chunk = (tid & 7) ^ (r0 & 7);
-    int pixbase[LA], iy0[LA], ix0[LA];
+    // ---- per-lane constants: wave w fills row groups w, w+NW, ...; inside a group lane l fills LDS slot
+    //      (row l>>3, physical chunk l&7), i.e. logical K-chunk (l&7) ^ (row&7) of that row ----
+    const int rl = lane >> 3;                  // row within the 8-row group (== row & 7)
+    const int chunk = (lane & 7) ^ rl;
+    const int KK = a.ksize * a.ksize;
     const int HoWo = a.Ho * a.Wo;
+    unsigned rowoff[LA];                       // byte offset of tap (0,0), channel chunk*8 (UNI) or 0 (per-lane tap)
+    unsigned tapmask[LA];                      // bit t set: tap t of this pixel lies inside the image
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        int m = pt * BP + r0 + i * RPP;
-        if (m < M) {
-            int n = m / HoWo;
-            int rem = m - n * HoWo;
-            int oy = rem / a.Wo;
-            int ox = rem - oy * a.Wo;
-            pixbase[i] = n * a.H * a.W;
-            iy0[i] = oy * a.stride - a.pad;
-            ix0[i] = ox * a.stride - a.pad;
-        } else {
-            pixbase[i] = 0; iy0[i] = -(1 << 20); ix0[i] = 0;
+        const int prow = (wid + i * NW) * 8 + rl;
+        const int m = pt * BP + prow;
+        unsigned mask = 0, off = 0;
+        if (m < M && prow < BP) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride + (UNI ? chunk * 8 : 0)) * 2u;
+            if (a.ksize == 3) {
+                unsigned ry = 0, cx = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    ry |= ((unsigned)(iy0 + d) < (unsigned)a.H ? 1u : 0u) << d;
+                    cx |= ((unsigned)(ix0 + d) < (unsigned)a.W ? 1u : 0u) << d;
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (ry & (1u << kh)) mask |= cx << (3 * kh);
+            } else if (a.ksize == 1) {
+                mask = ((unsigned)iy0 < (unsigned)a.H && (unsigned)ix0 < (unsigned)a.W) ? 1u : 0u;
+            } else {
+                for (int t = 0; t < KK; ++t) {
+                    const int kh = t / a.ksize, kw = t - kh * a.ksize;
+                    if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mask |= 1u << t;
+                }
+            }
         }
+        rowoff[i] = off;
+        tapmask[i] = mask;
     }
-    const bf16_t *wrow[LB];
+    unsigned woff[LB];
 #pragma unroll
-    for (int i = 0; i < LB; ++i)
-        wrow[i] = wt + (size_t)(ct * BC + r0 + i * RPP) * a.Kpad + chunk * 8;
+    for (int i = 0; i < LB; ++i) {
+        const int crow = (wid + i * NW) * 8 + rl;
+        woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * 8) * 2u : OOB_OFFSET;
+    }
 
-    const int KK = a.ksize * a.ksize;
-    int kc = chunk * 8, tap = 0;
-    while (kc >= a.Cin_pad) { kc -= a.Cin_pad; ++tap; }
+    // K cursor.  UNI: scalars (tap, kh, kw, channel base).  Otherwise per lane (chunk-dependent).
+    int s_tap = 0, s_kh = 0, s_kw = 0, s_kb = 0;        // UNI
+    int v_kc = chunk * 8, v_tap = 0;                    // !UNI
+    if (!UNI)
+        while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
+    int s_wk = 0;                                       // byte offset of the K-step in a filter row
 
-    // global -> LDS direct (global_load_lds_dwordx4): one wave instruction fills 8 tile rows (1 KiB)
-    auto stage = [&](int kt, int buf) {
-        int kh = 0, kw = 0;
-        if (a.ksize == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-        else if (a.ksize != 1) { kh = tap / a.ksize; kw = tap - kh * a.ksize; }
-        const bool tap_ok = tap < KK;
-        char *dx = sX + buf * (BP * 128) + wid * 1024;
-        char *dw = sW + buf * (BC * 128) + wid * 1024;
+    auto stage = [&](char *sbase) {
+        char *dx = sbase + wid * 1024;
+        char *dw = sbase + BPL * 128 + wid * 1024;
+        if (UNI) {
+            const unsigned tapbit = s_tap < KK ? 1u << s_tap : 0u;
+            const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_kb) * 2;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            int iy = iy0[i] + kh, ix = ix0[i] + kw;
-            bool ok = tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const bf16_t *p = ok ? in + ((size_t)(pixbase[i] + iy * a.W + ix) * a.in_stride + kc)
-                                 : (const bf16_t *)a.zeros;
-            __builtin_amdgcn_global_load_lds((glb_void *)p, (lds_void *)(dx + i * RPP * 128), 16, 0, 0);
+            for (int i = 0; i < LA; ++i) {
+                const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, soff, 0, 0);
+            }
+            s_kb += 64;
+            if (s_kb >= a.Cin_pad) { s_kb = 0; ++s_tap; if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; } }
+        } else {
+            int kh = 0, kw = 0;
+            if (a.ksize == 3) { kh = (v_tap * 11) >> 5; kw = v_tap - kh * 3; }
+            else if (a.ksize != 1) { kh = v_tap / a.ksize; kw = v_tap - kh * a.ksize; }
+            const unsigned tapbit = v_tap < KK ? 1u << v_tap : 0u;
+            const unsigned delta = (unsigned)((kh * a.W + kw) * a.in_stride + v_kc) * 2u;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] + delta : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, 0, 0, 0);
+            }
+            v_kc += 64;
+            while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(wrow[i] + (size_t)kt * 64), (lds_void *)(dw + i * RPP * 128), 16, 0, 0);
-        kc += 64;
-        while (kc >= a.Cin_pad) { kc -= a.Cin_pad; ++tap; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dw + i * NW * 1024), 16, woff[i], s_wk, 0, 0);
+        s_wk += 128;
     };
 
     f32x4 acc[TC][TP];
@@ -127,51 +180,61 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = a.Kpad / 64;
-    stage(0, 0);
-    __syncthreads();
+    constexpr int D = NS - 1;                  // prefetch distance in K-steps
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (t < KT) stage(smem + t * STAGE_BYTES);
 
     const int l15 = lane & 15, lq = lane >> 4;
+    // fragment read offsets inside a stage (two K-halves), constant over the loop
+    const int sw0 = ((0 + lq) ^ (l15 & 7)) << 4, sw1 = ((4 + lq) ^ (l15 & 7)) << 4;
+    const int offx = (wpi * TP * 16 + l15) * 128;
+    const int offw = BPL * 128 + (wci * TC * 16 + l15) * 128;
+    int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
-        const char *bx = sX + buf * (BP * 128) + (wpi * TP * 16 + l15) * 128;
-        const char *bw = sW + buf * (BC * 128) + (wci * TC * 16 + l15) * 128;
+        // K-step kt has landed once at most (D-1) younger K-steps' loads remain outstanding (in-order counter)
+        if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>();
+        block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
+        if (kt + D < KT) stage(smem + nxt * STAGE_BYTES);
+        const char *sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int sw = ((kk * 4 + lq) ^ (l15 & 7)) << 4;
+            const int sw = kk ? sw1 : sw0;
             bf16x8 fw[TC], fx[TP];
 #pragma unroll
-            for (int i = 0; i < TC; ++i) fw[i] = *(const bf16x8 *)(bw + i * 16 * 128 + sw);
+            for (int i = 0; i < TC; ++i) fw[i] = *(const bf16x8 *)(sb + offw + i * 2048 + sw);
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(bx + j * 16 * 128 + sw);
+            for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(sb + offx + j * 2048 + sw);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();      // drains this step's global_load_lds (vmcnt(0)) and orders LDS reuse
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
 
     // ---- epilogue: bias + activation (+ residual), 4 consecutive channels per lane ----
     const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+    const bool full = (pt * BP + BP <= M) && (ct * BC + BC <= a.Cout);     // no ragged edge in this tile
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int ch = ct * BC + (wci * TC + i) * 16 + lq * 4;
-        if (ch >= a.Cout) continue;
+        if (!full && ch >= a.Cout) continue;
         const float4 bv = *(const float4 *)(a.bias + ch);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int m = pt * BP + (wpi * TP + j) * 16 + l15;
-            if (m >= M) continue;
+            if (!full && m >= M) continue;
             float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
             if (a.act == ACT_LEAKY) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
             }
-            if (OUT_F32) {
+            if (a.out_f32) {
                 float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
-                if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
+                if (full || ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
                 else
                     for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];
             } else {
@@ -191,21 +254,26 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
             }
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
-struct CfgDesc { const char *name; int wp, wc, tp, tc; };
+struct CfgDesc { const char *name; int wp, wc, tp, tc, ns; };
 static const CfgDesc kCfgs[] = {
-    {"p128c128_w2x2", 2, 2, 4, 4},
-    {"p64c128_w2x2", 2, 2, 2, 4},
-    {"p256c32_w4x1", 4, 1, 4, 2},
-    {"p128c64_w2x2", 2, 2, 4, 2},
-    {"p256c64_w4x1", 4, 1, 4, 4},
-    {"p256c128_w4x2", 4, 2, 4, 4},
-    {"p128c256_w2x4", 2, 4, 4, 4},
-    {"p64c64_w2x2", 2, 2, 2, 2},
-    {"p256c256_w2x4", 2, 4, 8, 4},
-    {"p256c256_w4x2", 4, 2, 4, 8},
+    {"p128c128_s2", 2, 2, 4, 4, 2}, {"p128c128_s3", 2, 2, 4, 4, 3},
+    {"p64c128_s2", 2, 2, 2, 4, 2},  {"p64c128_s3", 2, 2, 2, 4, 3},
+    {"p256c32_s2", 4, 1, 4, 2, 2},  {"p256c32_s3", 4, 1, 4, 2, 3},
+    {"p128c64_s2", 2, 2, 4, 2, 2},  {"p128c64_s3", 2, 2, 4, 2, 3},
+    {"p256c64_s2", 4, 1, 4, 4, 2},  {"p256c64_s3", 4, 1, 4, 4, 3},
+    {"p256c128_s2", 4, 2, 4, 4, 2}, {"p256c128_s3", 4, 2, 4, 4, 3},
+    {"p128c256_s2", 2, 4, 4, 4, 2}, {"p128c256_s3", 2, 4, 4, 4, 3},
+    {"p64c64_s2", 2, 2, 2, 2, 2},   {"p64c64_s4", 2, 2, 2, 2, 4},
+    {"p256c256_s2", 2, 4, 8, 4, 2},
+    // pixel-tile heights that are not powers of two: picked by the autotuner when they make the tile count a near
+    // multiple of the 256 CUs x resident workgroups (wave quantisation), e.g. 176 px for M = 32 * 26 * 26
+    {"p176c128_s2", 1, 4, 11, 2, 2}, {"p176c256_s2", 1, 4, 11, 4, 2}, {"p176c64_s2", 1, 4, 11, 1, 2},
+    {"p160c128_s2", 1, 4, 10, 2, 2}, {"p192c128_s2", 1, 4, 12, 2, 2}, {"p144c128_s2", 1, 4, 9, 2, 2},
+    {"p208c128_s2", 1, 4, 13, 2, 2}, {"p96c128_s2", 1, 4, 6, 2, 2},   {"p112c128_s2", 1, 4, 7, 2, 2},
 };
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
 const char *conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) ? kCfgs[cfg].name : "?"; }
@@ -213,52 +281,73 @@ const char *conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) 
 int conv_pick_cfg(const ConvArgs &a)
 {
     const long M = (long)a.N * a.Ho * a.Wo;
-    if (a.Cout <= 32) return 2;
-    if (a.Cout <= 64) return M >= 65536 ? 4 : 3;
+    if (a.Cout <= 32) return 4;
+    if (a.Cout <= 64) return M >= 65536 ? 8 : 6;
     const long tiles128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (tiles128 < 512) return M < 8192 && tiles128 < 128 ? 7 : 1;
+    if (tiles128 < 512) return M < 8192 && tiles128 < 128 ? 14 : 2;
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC>
-static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
+template <int WP, int WC, int TP, int TC, int NS, bool UNI>
+static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
-    const size_t lds = 2 * (size_t)(BP + BC) * 128;
+    constexpr int NW = WP * WC;
+    constexpr int BPL = (BP / 8 + NW - 1) / NW * NW * 8, BCL = (BC / 8 + NW - 1) / NW * NW * 8;
+    constexpr size_t lds = (size_t)NS * (BPL + BCL) * 128;
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * WP * WC);   // multiple of 8: see the XCD mapping
-    if (a.out_f32) {
-        auto k = conv_igemm_bf16<WP, WC, TP, TC, true>;
-        if (lds > 65536) {
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) {
+        static bool done = false;      // per instantiation
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, UNI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
+            done = true;
         }
-        hipLaunchKernelGGL(k, grid, block, lds, s, a);
-    } else {
-        auto k = conv_igemm_bf16<WP, WC, TP, TC, false>;
-        if (lds > 65536) {
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(k, grid, block, lds, s, a);
     }
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, UNI>), grid, block, lds, s, a);
     return hipGetLastError();
+}
+
+template <int WP, int WC, int TP, int TC, int NS>
+static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
+{
+    // 32-bit buffer offsets: the activation window must stay below 2 GiB
+    if ((double)a.N * a.H * a.W * a.in_stride * 2.0 + 2.0 * (a.W + 1) * a.in_stride >= 2147483648.0) return hipErrorInvalidValue;
+    return (a.Cin_pad % 64) == 0 ? launch_u<WP, WC, TP, TC, NS, true>(a, s) : launch_u<WP, WC, TP, TC, NS, false>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
     switch (cfg) {
-    case 0: return launch_t<2, 2, 4, 4>(a, s);
-    case 1: return launch_t<2, 2, 2, 4>(a, s);
-    case 2: return launch_t<4, 1, 4, 2>(a, s);
-    case 3: return launch_t<2, 2, 4, 2>(a, s);
-    case 4: return launch_t<4, 1, 4, 4>(a, s);
-    case 5: return launch_t<4, 2, 4, 4>(a, s);
-    case 6: return launch_t<2, 4, 4, 4>(a, s);
-    case 7: return launch_t<2, 2, 2, 2>(a, s);
-    case 8: return launch_t<2, 4, 8, 4>(a, s);
-    case 9: return launch_t<4, 2, 4, 8>(a, s);
+    case 0: return launch_t<2, 2, 4, 4, 2>(a, s);
+    case 1: return launch_t<2, 2, 4, 4, 3>(a, s);
+    case 2: return launch_t<2, 2, 2, 4, 2>(a, s);
+    case 3: return launch_t<2, 2, 2, 4, 3>(a, s);
+    case 4: return launch_t<4, 1, 4, 2, 2>(a, s);
+    case 5: return launch_t<4, 1, 4, 2, 3>(a, s);
+    case 6: return launch_t<2, 2, 4, 2, 2>(a, s);
+    case 7: return launch_t<2, 2, 4, 2, 3>(a, s);
+    case 8: return launch_t<4, 1, 4, 4, 2>(a, s);
+    case 9: return launch_t<4, 1, 4, 4, 3>(a, s);
+    case 10: return launch_t<4, 2, 4, 4, 2>(a, s);
+    case 11: return launch_t<4, 2, 4, 4, 3>(a, s);
+    case 12: return launch_t<2, 4, 4, 4, 2>(a, s);
+    case 13: return launch_t<2, 4, 4, 4, 3>(a, s);
+    case 14: return launch_t<2, 2, 2, 2, 2>(a, s);
+    case 15: return launch_t<2, 2, 2, 2, 4>(a, s);
+    case 16: return launch_t<2, 4, 8, 4, 2>(a, s);
+    case 17: return launch_t<1, 4, 11, 2, 2>(a, s);
+    case 18: return launch_t<1, 4, 11, 4, 2>(a, s);
+    case 19: return launch_t<1, 4, 11, 1, 2>(a, s);
+    case 20: return launch_t<1, 4, 10, 2, 2>(a, s);
+    case 21: return launch_t<1, 4, 12, 2, 2>(a, s);
+    case 22: return launch_t<1, 4, 9, 2, 2>(a, s);
+    case 23: return launch_t<1, 4, 13, 2, 2>(a, s);
+    case 24: return launch_t<1, 4, 6, 2, 2>(a, s);
+    case 25: return launch_t<1, 4, 7, 2, 2>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
