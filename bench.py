@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +97,22 @@ def main():
     counts = torch.zeros((B,), dtype=torch.int32, device=dev)
     records = torch.zeros((B, 1 + max_out * 6), dtype=torch.int32, device=dev)
     eng.forward(images, want_detections=False)
-    eng.autotune(B, 3)
+    # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
+    tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_bf16.json" % (args.size, B))
+    loaded = False
+    if os.path.exists(tuned) and not args.retune:
+        try:
+            plan = json.load(open(tuned))
+            if plan.get("num_cfgs") == hip.op_conv_num_cfgs() and len(plan["cfgs"]) == eng.num_layers:
+                eng.set_tile_configs(plan["cfgs"]); loaded = True
+        except Exception:      # noqa: BLE001
+            loaded = False
+    if not loaded:
+        eng.autotune(B, 5)
+        if rank == 0:
+            out_dir = os.path.join(ROOT, "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
+            json.dump({"num_cfgs": hip.op_conv_num_cfgs(), "cfgs": [int(v) for v in eng.get_tile_configs()]},
+                      open(os.path.join(out_dir, os.path.basename(tuned)), "w"))
 
     def step():
         eng.forward(images, want_detections=False)
@@ -131,6 +147,13 @@ def main():
 
     if rank == 0:
         total_ms, conv_ms = eng.time_forward(B, 10, conv=True)
+        traffic = None      # HBM bytes per forward of the conv launches, from the committed PMC passes (cannot be read in-process)
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if args.size == 416 and B == 32 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))["conv_hbm_bytes_per_forward"]
+            except Exception:      # noqa: BLE001
+                traffic = None
         flops = eng.conv_flops() * B
         achieved = flops / (conv_ms * 1e-3) / 1e12
         out = {
@@ -144,7 +167,7 @@ def main():
             "p50_ms_per_image": round(float(np.median(step_ms)) / B, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv_igemm_bf16 (75 launches/forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }

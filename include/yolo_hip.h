@@ -153,6 +153,10 @@ int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *c
 int yolo_time_layers(yolo_ctx *ctx, int n, int iters, float *ms_out);
 /* Tries every conv tile configuration on every conv layer at batch n and keeps the fastest. */
 int yolo_autotune(yolo_ctx *ctx, int n, int iters);
+/* Read / restore the per-layer tile choices (one int per layer, -1 for non-conv layers or "library default") so a
+ * tuned plan can be persisted by the caller.  cfgs has yolo_num_layers() entries. */
+int yolo_get_tile_configs(const yolo_ctx *ctx, int32_t *cfgs);
+int yolo_set_tile_configs(yolo_ctx *ctx, const int32_t *cfgs);
 
 /* ---- single operators on host buffers (parity tests call the production kernels through these) - */
 /* x [n,h,w,cin] fp32 NHWC, w_hwio [k,k,cin,cout], bias [cout] (or NULL), residual [n,ho,wo,cout] or NULL.

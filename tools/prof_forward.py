@@ -8,8 +8,12 @@ txt = IO.with_input_size(IO.cfg_text("yolov3"), size); secs = IO.parse_cfg(txt)
 eng = hip.Engine(txt, max_batch=B); eng.set_weights(IO.synth_weights(secs, 0))
 img = np.random.default_rng(0).integers(0, 256, (B, size, size, 3), dtype=np.uint8)
 eng.forward(img, want_detections=False)
-if os.environ.get("TUNE", "1") == "1":
+import json
+plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_bf16.json" % (size, B))
+if os.environ.get("TUNE", "0") == "1" or not os.path.exists(plan):
     eng.autotune(B, 3)
+else:
+    eng.set_tile_configs(json.load(open(plan))["cfgs"])
 for _ in range(iters):
     eng.forward(img, want_detections=False)
 eng.postprocess(B)

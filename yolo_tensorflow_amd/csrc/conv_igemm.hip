@@ -35,6 +35,11 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
+__device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t shift)
+{
+    return shift == 255 ? n : (int)(__umulhi((uint32_t)n, mul) >> shift);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
@@ -98,9 +103,9 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         const int m = pt * BP + prow;
         unsigned mask = 0, off = 0;
         if (m < M && prow < BP) {
-            const int n = m / HoWo;
+            const int n = fast_div(m, a.howo_mul, a.howo_shift);
             const int rem = m - n * HoWo;
-            const int oy = rem / a.Wo;
+            const int oy = fast_div(rem, a.wo_mul, a.wo_shift);
             const int ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
             off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride + (UNI ? chunk * 8 : 0)) * 2u;
@@ -258,6 +263,103 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// First layer (3x3, stride 1, 3 real input channels padded to 8): HBM-bound (it writes N*H*W*Cout bf16), K is only
+// 9 taps x 8 channels = 72 (padded to 96).  No LDS: a lane's MFMA B fragment for K-group (kk, lq) is exactly the
+// 16-byte channel vector of ONE input pixel (tap kk*4+lq), so it is a single global_load_dwordx4; the filters
+// (Cout x 96 bf16) live in registers for the whole wave.  One wave computes 16 pixels x Cout per step.
+template <int TC>
+__global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int M = a.N * a.Ho * a.Wo;
+    const int tiles = (M + 15) / 16;
+    const bf16_t *__restrict__ in = (const bf16_t *)a.in;
+    const bf16_t *__restrict__ wt = (const bf16_t *)a.wt;
+
+    // filters: A fragment (i, kk) = W[channel i*16 + l15][k = (kk*4 + lq)*8 .. +7]; Kpad >= 96 holds zeros past k = 72
+    bf16x8 fw[TC][3];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            fw[i][kk] = *(const bf16x8 *)(wt + (size_t)(i * 16 + l15) * a.Kpad + (kk * 4 + lq) * 8);
+    float4 bv[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) bv[i] = *(const float4 *)(a.bias + i * 16 + lq * 4);
+
+    const int HoWo = a.Ho * a.Wo;
+    constexpr int U = 4;                        // 16-pixel tiles in flight per wave (memory-level parallelism)
+    const long groups = (tiles + U - 1) / U;
+    for (long g = wave; g < groups; g += nwaves) {
+        bf16x8 fx[U][3];
+        int mrow[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = (int)(g * U + u) * 16 + l15;
+            const bool mv = m < M;
+            mrow[u] = mv ? m : -1;
+            const int mm = mv ? m : M - 1;
+            const int n = fast_div(mm, a.howo_mul, a.howo_shift), rem = mm - n * HoWo;
+            const int oy = fast_div(rem, a.wo_mul, a.wo_shift), ox = rem - oy * a.Wo;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int tap = kk * 4 + lq;
+                const int kh = (tap * 11) >> 5, kw = tap - kh * 3;
+                const int iy = oy + kh - 1, ix = ox + kw - 1;
+                const bool ok = mv && tap < 9 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const bf16_t *p = ok ? in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_stride : (const bf16_t *)a.zeros;
+                fx[u][kk] = *(const bf16x8 *)p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 acc[TC];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][kk], fx[u][kk], acc[i], 0, 0, 0);
+            }
+            if (mrow[u] >= 0) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    float v[4] = {acc[i][0] + bv[i].x, acc[i][1] + bv[i].y, acc[i][2] + bv[i].z, acc[i][3] + bv[i].w};
+                    if (a.act == ACT_LEAKY)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    uint2 pk;
+                    pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
+                    pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
+                    *(uint2 *)((bf16_t *)a.out + (size_t)mrow[u] * a.out_stride + i * 16 + lq * 4) = pk;
+                }
+            }
+        }
+    }
+#endif
+}
+
+bool conv_c8_direct_ok(const ConvArgs &a)
+{
+    return a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin_pad == 8 && !a.out_f32 && !a.res && a.Kpad >= 96 &&
+           (a.Cout == 16 || a.Cout == 32 || a.Cout == 64);
+}
+
+hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
+{
+    const long M = (long)a.N * a.Ho * a.Wo;
+    long waves = (M + 63) / 64;
+    long blocks = (waves + 3) / 4; if (blocks > 256 * 8) blocks = 256 * 8;
+    dim3 grid((unsigned)blocks), block(256);
+    if (a.Cout == 16) hipLaunchKernelGGL((conv_c8_3x3_direct<1>), grid, block, 0, s, a);
+    else if (a.Cout == 32) hipLaunchKernelGGL((conv_c8_3x3_direct<2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_c8_3x3_direct<4>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 struct CfgDesc { const char *name; int wp, wc, tp, tc, ns; };
 static const CfgDesc kCfgs[] = {
     {"p128c128_s2", 2, 2, 4, 4, 2}, {"p128c128_s3", 2, 2, 4, 4, 3},
@@ -280,6 +382,7 @@ const char *conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) 
 
 int conv_pick_cfg(const ConvArgs &a)
 {
+    if (conv_c8_direct_ok(a)) return CONV_CFG_DIRECT;
     const long M = (long)a.N * a.Ho * a.Wo;
     if (a.Cout <= 32) return 4;
     if (a.Cout <= 64) return M >= 65536 ? 8 : 6;
@@ -321,6 +424,7 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
+    if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
     switch (cfg) {
     case 0: return launch_t<2, 2, 4, 4, 2>(a, s);
     case 1: return launch_t<2, 2, 4, 4, 3>(a, s);

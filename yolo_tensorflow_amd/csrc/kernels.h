@@ -29,9 +29,26 @@ struct ConvArgs {
     int Kpad;                            // multiple of 64
     int act;
     const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
+    // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
+    uint32_t howo_mul, howo_shift, wo_mul, wo_shift;
 };
+// host helper: derives the division constants from Ho, Wo (call after filling the geometry)
+inline void conv_finalize(ConvArgs &a)
+{
+    auto magic = [](uint32_t d, uint32_t &mul, uint32_t &shift) {
+        if (d <= 1) { mul = 0; shift = 255; return; }
+        uint32_t l = 0; while ((1u << l) < d) ++l;          // ceil(log2 d)
+        const unsigned k = 31 + l;
+        mul = (uint32_t)(((unsigned long long)1 << k) / d + 1);
+        shift = k - 32;
+    };
+    magic((uint32_t)(a.Ho * a.Wo), a.howo_mul, a.howo_shift);
+    magic((uint32_t)a.Wo, a.wo_mul, a.wo_shift);
+}
 
 // bf16 MFMA implicit-GEMM conv.  cfg in [0, conv_num_cfgs()); returns hipError.
+#define CONV_CFG_DIRECT 1000          // first-layer direct kernel (Cin padded 3 -> 8), outside the tile table
+bool conv_c8_direct_ok(const ConvArgs &a);
 int conv_num_cfgs();
 const char *conv_cfg_name(int cfg);
 // rough preference used when no autotune ran

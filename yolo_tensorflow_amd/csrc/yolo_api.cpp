@@ -359,6 +359,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
     a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
     a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = L.act; a.zeros = c->d_zeros;
+    conv_finalize(a);
     return a;
 }
 
@@ -371,7 +372,11 @@ int run_layer(yolo_ctx *c, int i, int n)
     case L_CONV: {
         ConvArgs a = conv_args(c, L, n);
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
-        else { int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a); HIPCK(c, launch_conv_bf16(a, cfg, s)); }
+        else {
+            int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
+            if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
+            HIPCK(c, launch_conv_bf16(a, cfg, s));
+        }
         break; }
     case L_SHORTCUT:
         if (!L.noop) HIPCK(c, launch_add(nview(view_of(c, L.in[0])), nview(view_of(c, L.in[1])), nview(L.out), s));
@@ -739,7 +744,9 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         auto it = memo.find(key);
         if (it != memo.end()) { L.tile_cfg = it->second; continue; }
         float best = 1e30f; int best_cfg = conv_pick_cfg(a);
-        for (int cfg = 0; cfg < conv_num_cfgs(); ++cfg) {
+        for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
+            const int cfg = ci == conv_num_cfgs() ? CONV_CFG_DIRECT : ci;
+            if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) continue;
             if (launch_conv_bf16(a, cfg, c->stream) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm-up
             HIPCK(c, hipEventRecord(e0, c->stream));
             for (int r = 0; r < iters; ++r) launch_conv_bf16(a, cfg, c->stream);
@@ -751,6 +758,25 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         L.tile_cfg = best_cfg; memo[key] = best_cfg;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return YOLO_OK;
+}
+
+int yolo_get_tile_configs(const yolo_ctx *c, int32_t *cfgs)
+{
+    if (!c || !cfgs) return YOLO_ERR_INVALID;
+    for (size_t i = 0; i < c->layers.size(); ++i) cfgs[i] = c->layers[i].type == L_CONV ? c->layers[i].tile_cfg : -1;
+    return YOLO_OK;
+}
+
+int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
+{
+    if (!c || !cfgs) return YOLO_ERR_INVALID;
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        if (c->layers[i].type != L_CONV) continue;
+        const int v = cfgs[i];
+        if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
+        c->layers[i].tile_cfg = v;
+    }
     return YOLO_OK;
 }
 
@@ -791,6 +817,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     a.in = d_x; a.in_stride = L.cin_pad; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = cstride; a.out_f32 = f32;
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = act; a.zeros = d_z;
+    conv_finalize(a);
     hipError_t e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
     if (!S.ok(e)) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
     if (!S.ok(launch_to_f32(make_view(d_o, n, ho, wo, cout, cstride, f32), d_o32, S.s))) { g_op_err = S.err; return S.rc; }

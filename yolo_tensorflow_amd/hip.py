@@ -27,7 +27,7 @@ EXPORTS = [
     "yolo_weights_count", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
-    "yolo_autotune", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
+    "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_decode", "yolo_op_postprocess",
 ]
 
@@ -75,6 +75,8 @@ def load_library():
     l.yolo_time_forward.argtypes = [P, I, I, FP, FP]
     l.yolo_time_layers.argtypes = [P, I, I, FP]
     l.yolo_autotune.argtypes = [P, I, I]
+    l.yolo_get_tile_configs.argtypes = [P, P]
+    l.yolo_set_tile_configs.argtypes = [P, P]
     l.yolo_op_conv2d.argtypes = [P, I, I, I, I, P, P, I, I, I, I, P, P, I, I, I]
     l.yolo_op_conv_num_cfgs.argtypes = []
     l.yolo_op_upsample2x.argtypes = [P, I, I, I, I, I, P, I]
@@ -230,6 +232,17 @@ class Engine:
 
     def autotune(self, n, iters=3):
         self._check(self.lib.yolo_autotune(self.ctx, n, iters), "yolo_autotune")
+
+    def get_tile_configs(self):
+        cfgs = np.full(self.num_layers, -1, dtype=np.int32)
+        self._check(self.lib.yolo_get_tile_configs(self.ctx, cfgs.ctypes.data), "yolo_get_tile_configs")
+        return cfgs
+
+    def set_tile_configs(self, cfgs):
+        cfgs = np.ascontiguousarray(cfgs, dtype=np.int32)
+        if cfgs.size != self.num_layers:
+            raise YoloError("need %d tile configs, got %d" % (self.num_layers, cfgs.size))
+        self._check(self.lib.yolo_set_tile_configs(self.ctx, cfgs.ctypes.data), "yolo_set_tile_configs")
 
 
 # ---- single operators (host buffers in, host buffers out; production kernels underneath) ----------
