@@ -48,7 +48,7 @@ __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "
 
 // UNI: Cin_pad is a multiple of 64, so all 8 chunks of a K-step belong to one tap (scalar tap cursor).
 // otherwise (Cin_pad = 8, 16, 32, ...): the chunks of one K-step span several taps, tap cursor is per lane.
-template <int WP, int WC, int TP, int TC, int NS, bool UNI>
+template <int WP, int WC, int TP, int TC, int NS, bool UNI, bool DIAG = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -59,7 +59,13 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     constexpr int GP = BP / 8, GC = BC / 8;    // 8-row groups (one wave-level LDS-DMA instruction each)
     // every wave issues the same number of LDS-DMA instructions per K-step (the counted vmcnt relies on it): group
     // counts are padded up to a multiple of the wave count; padded rows get an out-of-range offset (zeros, no traffic)
-    constexpr int LA = (GP + NW - 1) / NW, LB = (GC + NW - 1) / NW;
+    // Experiment kept for the record (disabled): with WP == 1 no filter row is shared between waves, so the filter
+    // fragments could go global -> VGPR directly (one K-step ahead, ping-pong registers) and skip LDS.  Measured on
+    // MI355X it is SLOWER (K-step 2114 -> 2900 cycles for p176c128): a fragment-shaped load touches 16 rows x 64 B per
+    // instruction, which the texture addresser handles far worse than the 8 x 128-B rows of an LDS-DMA piece.
+    constexpr bool WDIRECT = false;
+    static_assert(!WDIRECT || NS == 2, "direct filter fragments are pipelined exactly one K-step ahead");
+    constexpr int LA = (GP + NW - 1) / NW, LB = WDIRECT ? 0 : (GC + NW - 1) / NW;
     constexpr int L = LA + LB;
     constexpr int BPL = LA * NW * 8, BCL = LB * NW * 8;      // rows of the LDS images
     constexpr int STAGE_BYTES = (BPL + BCL) * 128;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         rowoff[i] = off;
         tapmask[i] = mask;
     }
-    unsigned woff[LB];
+    unsigned woff[LB > 0 ? LB : 1];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int crow = (wid + i * NW) * 8 + rl;
@@ -144,6 +150,18 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     if (!UNI)
         while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
     int s_wk = 0;                                       // byte offset of the K-step in a filter row
+    // direct filter fragments: lane (l15, lq) of tile i needs W[ct*BC + (wci*TC+i)*16 + l15][k0 + (kk*4+lq)*8 .. +7]
+    unsigned wfoff[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+        wfoff[i] = (unsigned)((ct * BC + (wci * TC + i) * 16 + (lane & 15)) * a.Kpad + (lane >> 4) * 8) * 2u;
+    auto load_wfrag = [&](bf16x8 (&dst)[TC][2], int koff_bytes) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            dst[i][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wfoff[i], koff_bytes, 0));
+            dst[i][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wfoff[i] + 64u, koff_bytes, 0));
+        }
+    };
 
     auto stage = [&](char *sbase) {
         char *dx = sbase + wid * 1024;
@@ -189,6 +207,8 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 #pragma unroll
     for (int t = 0; t < D; ++t)
         if (t < KT) stage(smem + t * STAGE_BYTES);
+    bf16x8 fwc[TC][2], fwn[TC][2];             // WDIRECT: filter fragments of the current / next K-step
+    if (WDIRECT) load_wfrag(fwc, 0);
 
     const int l15 = lane & 15, lq = lane >> 4;
     // fragment read offsets inside a stage (two K-halves), constant over the loop
@@ -196,18 +216,37 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     const int offx = (wpi * TP * 16 + l15) * 128;
     const int offw = BPL * 128 + (wci * TC * 16 + l15) * 128;
     int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
-    for (int kt = 0; kt < KT; ++kt) {
+    // DIAG (separate diagnostic instantiation, never the shipped kernel): s_memtime stamps around the phases of a K-step
+    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t = 0;
+        if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+        return t;
+    };
+    if (DIAG) t_all0 = stamp();
+    // one K-step; `fcur` / `fnext` are the filter-fragment register sets of this and the next step (WDIRECT only: the
+    // loop is unrolled by two so the sets ping-pong without a copy, which would force an early wait on the loads)
+    auto kstep = [&](int kt, bf16x8 (&fcur)[TC][2], bf16x8 (&fnext)[TC][2]) {
+        const unsigned long long s0 = stamp();
         // K-step kt has landed once at most (D-1) younger K-steps' loads remain outstanding (in-order counter)
         if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>();
         block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
-        if (kt + D < KT) stage(smem + nxt * STAGE_BYTES);
+        const unsigned long long s1 = stamp();
+        if (kt + D < KT) {
+            stage(smem + nxt * STAGE_BYTES);
+            if (WDIRECT) load_wfrag(fnext, (kt + 1) * 128);
+        }
+        const unsigned long long s2 = stamp();
         const char *sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw = kk ? sw1 : sw0;
             bf16x8 fw[TC], fx[TP];
 #pragma unroll
-            for (int i = 0; i < TC; ++i) fw[i] = *(const bf16x8 *)(sb + offw + i * 2048 + sw);
+            for (int i = 0; i < TC; ++i) {
+                if (WDIRECT) fw[i] = fcur[i][kk];
+                else fw[i] = *(const bf16x8 *)(sb + offw + i * 2048 + sw);
+            }
 #pragma unroll
             for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(sb + offx + j * 2048 + sw);
 #pragma unroll
@@ -216,50 +255,118 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
+        if (DIAG) {
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            const unsigned long long s3 = stamp();
+            t_wait += s1 - s0; t_issue += s2 - s1; t_mma += s3 - s2;
+        }
         cur = cur + 1 == NS ? 0 : cur + 1;
         nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) { kstep(kt, fwc, fwn); kstep(kt + 1, fwn, fwc); }
+        if (kt < KT) kstep(kt, fwc, fwn);
     }
+    unsigned long long t_loop_end = 0;
+    if (DIAG) t_loop_end = stamp();
 
-    // ---- epilogue: bias + activation (+ residual), 4 consecutive channels per lane ----
-    const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+    // ---- epilogue ----
     const bool full = (pt * BP + BP <= M) && (ct * BC + BC <= a.Cout);     // no ragged edge in this tile
+    if (!a.out_f32) {
+        // bf16 output: bias + activation in registers, then the tile goes through LDS so that global stores (and the
+        // residual loads) are 16 B per lane along the channel axis -- whole 128-B lines per pixel instead of 16
+        // scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are issue-bound: ~600 cycles each).
+        constexpr int RS = BC * 2 + 16;                       // padded LDS row (bytes)
+        block_barrier();                                      // every wave is done reading the last stage
 #pragma unroll
-    for (int i = 0; i < TC; ++i) {
-        const int ch = ct * BC + (wci * TC + i) * 16 + lq * 4;
-        if (!full && ch >= a.Cout) continue;
-        const float4 bv = *(const float4 *)(a.bias + ch);
+        for (int i = 0; i < TC; ++i) {
+            const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
+            const float4 bv = *(const float4 *)(a.bias + ct * BC + chl);
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int m = pt * BP + (wpi * TP + j) * 16 + l15;
-            if (!full && m >= M) continue;
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (a.act == ACT_LEAKY) {
+            for (int j = 0; j < TP; ++j) {
+                float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+                if (a.act == ACT_LEAKY) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
-            }
-            if (a.out_f32) {
-                float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
-                if (full || ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
-                else
-                    for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];
-            } else {
-                if (res) {
-                    const uint2 rv = *(const uint2 *)(res + (size_t)m * a.res_stride + ch);
-                    // the layer's own output is rounded to bf16 first, exactly as if it had been stored
-                    // and re-read by a separate shortcut kernel, then the add is rounded once more
-                    v[0] = bf16_bits_to_f32(f32_to_bf16_rn(v[0])) + bf16_bits_to_f32(rv.x & 0xffff);
-                    v[1] = bf16_bits_to_f32(f32_to_bf16_rn(v[1])) + bf16_bits_to_f32(rv.x >> 16);
-                    v[2] = bf16_bits_to_f32(f32_to_bf16_rn(v[2])) + bf16_bits_to_f32(rv.y & 0xffff);
-                    v[3] = bf16_bits_to_f32(f32_to_bf16_rn(v[3])) + bf16_bits_to_f32(rv.y >> 16);
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                 }
                 uint2 pk;
                 pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
                 pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
-                *(uint2 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = pk;
+                *(uint2 *)(smem + ((wpi * TP + j) * 16 + l15) * RS + chl * 2) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();
+        const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+        constexpr int CPR = BC / 8;                           // 16-B chunks per tile row
+        constexpr int NT = 64 * NW;
+        for (int c = tid; c < BP * CPR; c += NT) {
+            const int row = c / CPR, cc = c - row * CPR;
+            const int m = pt * BP + row, ch = ct * BC + cc * 8;
+            if (!full && (m >= M || ch >= a.Cout)) continue;
+            uint4 o = *(const uint4 *)(smem + row * RS + cc * 16);
+            if (res) {
+                // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
+                // by a separate shortcut kernel; the sum is rounded once more
+                const uint4 r = *(const uint4 *)(res + (size_t)m * a.res_stride + ch);
+                uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = bf16_bits_to_f32(ov[q] & 0xffff) + bf16_bits_to_f32(rv[q] & 0xffff);
+                    const float hi = bf16_bits_to_f32(ov[q] >> 16) + bf16_bits_to_f32(rv[q] >> 16);
+                    ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
+                }
+                o = uint4{ov[0], ov[1], ov[2], ov[3]};
+            }
+            *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
+        }
+    } else {
+        // fp32 output (detection heads, Cout = 255): 4 consecutive channels per lane, 16-B stores
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int ch = ct * BC + (wci * TC + i) * 16 + lq * 4;
+            if (ch >= a.Cout) continue;
+            const float4 bv = *(const float4 *)(a.bias + ch);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int m = pt * BP + (wpi * TP + j) * 16 + l15;
+                if (m >= M) continue;
+                float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+                if (a.act == ACT_LEAKY) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                }
+                float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
+                if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
+                else
+                    for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];
             }
         }
     }
+    if (DIAG && a.dbg && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = stamp();
+        unsigned long long *d = a.dbg + ((size_t)tile * NW + wid) * 6;
+        d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end; d[5] = (unsigned long long)KT;
+    }
 #endif
+}
+
+hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
+{
+    // diagnostic instantiation of ONE configuration (p176c128_s2, uniform tap)
+    constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2;
+    constexpr int BP = WP * TP * 16, BC = WC * TC * 16, NW = WP * WC;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
+    constexpr int BPL = (BP / 8 + NW - 1) / NW * NW * 8, BCL = (BC / 8 + NW - 1) / NW * NW * 8;
+    constexpr size_t lds0 = (size_t)NS * (BPL + BCL) * 128, ldso = (size_t)BP * (BC * 2 + 16);
+    constexpr size_t lds = lds0 > ldso ? lds0 : ldso;
+    static bool done = false;
+    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,7 +477,7 @@ static const CfgDesc kCfgs[] = {
     {"p256c128_s2", 4, 2, 4, 4, 2}, {"p256c128_s3", 4, 2, 4, 4, 3},
     {"p128c256_s2", 2, 4, 4, 4, 2}, {"p128c256_s3", 2, 4, 4, 4, 3},
     {"p64c64_s2", 2, 2, 2, 2, 2},   {"p64c64_s4", 2, 2, 2, 2, 4},
-    {"p256c256_s2", 2, 4, 8, 4, 2},
+    {"p256c128_s2b", 4, 2, 4, 4, 2},
     // pixel-tile heights that are not powers of two: picked by the autotuner when they make the tile count a near
     // multiple of the 256 CUs x resident workgroups (wave quantisation), e.g. 176 px for M = 32 * 26 * 26
     {"p176c128_s2", 1, 4, 11, 2, 2}, {"p176c256_s2", 1, 4, 11, 4, 2}, {"p176c64_s2", 1, 4, 11, 1, 2},
@@ -399,7 +506,8 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr int NW = WP * WC;
     constexpr int BPL = (BP / 8 + NW - 1) / NW * NW * 8, BCL = (BC / 8 + NW - 1) / NW * NW * 8;
-    constexpr size_t lds = (size_t)NS * (BPL + BCL) * 128;
+    constexpr size_t lds0 = (size_t)NS * (BPL + BCL) * 128, ldso = (size_t)BP * (BC * 2 + 16);
+    constexpr size_t lds = lds0 > ldso ? lds0 : ldso;      // the epilogue's output tile re-uses the staging LDS
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * WP * WC);   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
         static bool done = false;      // per instantiation
@@ -442,7 +550,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     case 13: return launch_t<2, 4, 4, 4, 3>(a, s);
     case 14: return launch_t<2, 2, 2, 2, 2>(a, s);
     case 15: return launch_t<2, 2, 2, 2, 4>(a, s);
-    case 16: return launch_t<2, 4, 8, 4, 2>(a, s);
+    case 16: return launch_t<4, 2, 4, 4, 2>(a, s);
     case 17: return launch_t<1, 4, 11, 2, 2>(a, s);
     case 18: return launch_t<1, 4, 11, 4, 2>(a, s);
     case 19: return launch_t<1, 4, 11, 1, 2>(a, s);

@@ -31,6 +31,7 @@ struct ConvArgs {
     const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
     // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
     uint32_t howo_mul, howo_shift, wo_mul, wo_shift;
+    unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
 };
 // host helper: derives the division constants from Ho, Wo (call after filling the geometry)
 inline void conv_finalize(ConvArgs &a)
@@ -54,6 +55,7 @@ const char *conv_cfg_name(int cfg);
 // rough preference used when no autotune ran
 int conv_pick_cfg(const ConvArgs &a);
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
+hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 

@@ -818,7 +818,20 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = act; a.zeros = d_z;
     conv_finalize(a);
-    hipError_t e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
+    hipError_t e;
+    if (!f32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % 64 == 0) {
+        // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build, printed to stderr
+        const long tiles = (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
+        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * 4 * 6 * 8);
+        for (int rep = 0; rep < 3; ++rep) e = launch_conv_diag(a, S.s);
+        std::vector<unsigned long long> hd((size_t)tiles * 4 * 6);
+        S.download(hd.data(), a.dbg, hd.size() * 8);
+        double w = 0, is = 0, mm = 0, lp = 0, ep = 0; size_t cnt = hd.size() / 6;
+        for (size_t i = 0; i < cnt; ++i) { w += hd[i * 6]; is += hd[i * 6 + 1]; mm += hd[i * 6 + 2]; lp += hd[i * 6 + 3]; ep += hd[i * 6 + 4]; }
+        fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles\n",
+                cnt, hd[5], w / cnt / hd[5], is / cnt / hd[5], mm / cnt / hd[5], lp / cnt / hd[5], ep / cnt);
+    } else
+        e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
     if (!S.ok(e)) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
     if (!S.ok(launch_to_f32(make_view(d_o, n, ho, wo, cout, cstride, f32), d_o32, S.s))) { g_op_err = S.err; return S.rc; }
     S.download(out, d_o32, (size_t)n * ho * wo * cout * 4);
