@@ -23,6 +23,7 @@
 //   * NS-stage LDS ring: the loads of K-step t+NS-1 are issued before the MFMAs of step t; a counted
 //     s_waitcnt vmcnt + one raw s_barrier per K-step keep them in flight across the barrier.
 #include "kernels.h"
+#include <cstdio>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +49,7 @@ __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "
 
 // UNI: Cin_pad is a multiple of 64, so all 8 chunks of a K-step belong to one tap (scalar tap cursor).
 // otherwise (Cin_pad = 8, 16, 32, ...): the chunks of one K-step span several taps, tap cursor is per lane.
-template <int WP, int WC, int TP, int TC, int NS, bool UNI, bool DIAG = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, bool DIAG = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     constexpr int NW = WP * WC;
     constexpr int BP = WP * TP * 16;           // output pixels per workgroup
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
-    constexpr int GP = BP / 8, GC = BC / 8;    // 8-row groups (one wave-level LDS-DMA instruction each)
+    static_assert(BK == 64 || BK == 32, "K-step");
+    constexpr int RB = BK * 2;                 // bytes of one LDS tile row (one K-step of one pixel / filter)
+    constexpr int CPRW = RB / 16;              // 16-B chunks per row: 8 or 4
+    constexpr int RG = 64 / CPRW;              // rows filled by one wave-level LDS-DMA instruction: 8 or 16
+    constexpr int GP = (BP + RG - 1) / RG, GC = (BC + RG - 1) / RG;
     // every wave issues the same number of LDS-DMA instructions per K-step (the counted vmcnt relies on it): group
     // counts are padded up to a multiple of the wave count; padded rows get an out-of-range offset (zeros, no traffic)
     // Experiment kept for the record (disabled): with WP == 1 no filter row is shared between waves, so the filter
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     static_assert(!WDIRECT || NS == 2, "direct filter fragments are pipelined exactly one K-step ahead");
     constexpr int LA = (GP + NW - 1) / NW, LB = WDIRECT ? 0 : (GC + NW - 1) / NW;
     constexpr int L = LA + LB;
-    constexpr int BPL = LA * NW * 8, BCL = LB * NW * 8;      // rows of the LDS images
-    constexpr int STAGE_BYTES = (BPL + BCL) * 128;
+    constexpr int BPL = LA * NW * RG, BCL = LB * NW * RG;    // rows of the LDS images
+    constexpr int STAGE_BYTES = (BPL + BCL) * RB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][ BP rows | BC rows ][128 B]
 
@@ -97,15 +102,18 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 
     // ---- per-lane constants: wave w fills row groups w, w+NW, ...; inside a group lane l fills LDS slot
     //      (row l>>3, physical chunk l&7), i.e. logical K-chunk (l&7) ^ (row&7) of that row ----
-    const int rl = lane >> 3;                  // row within the 8-row group (== row & 7)
-    const int chunk = (lane & 7) ^ rl;
+    // LDS-DMA is lane-linear: lane l fills row (l / CPRW) of its row group, physical chunk (l % CPRW).  The chunk swizzle
+    // that makes the ds_read_b128 fragment reads conflict-free is therefore applied to the SOURCE chunk:
+    //   BK = 64 (128-B rows): phys = chunk ^ (row & 7);   BK = 32 (64-B rows): phys = chunk ^ (3 * ((row >> 2) & 1))
+    const int rl = lane / CPRW;                // row within the row group (group bases are multiples of RG)
+    const int chunk = BK == 64 ? ((lane & 7) ^ (rl & 7)) : ((lane & 3) ^ (3 * ((rl >> 2) & 1)));
     const int KK = a.ksize * a.ksize;
     const int HoWo = a.Ho * a.Wo;
     unsigned rowoff[LA];                       // byte offset of tap (0,0), channel chunk*8 (UNI) or 0 (per-lane tap)
     unsigned tapmask[LA];                      // bit t set: tap t of this pixel lies inside the image
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int prow = (wid + i * NW) * 8 + rl;
+        const int prow = (wid + i * NW) * RG + rl;
         const int m = pt * BP + prow;
         unsigned mask = 0, off = 0;
         if (m < M && prow < BP) {
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     unsigned woff[LB > 0 ? LB : 1];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int crow = (wid + i * NW) * 8 + rl;
+        const int crow = (wid + i * NW) * RG + rl;
         woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * 8) * 2u : OOB_OFFSET;
     }
 
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 
     auto stage = [&](char *sbase) {
         char *dx = sbase + wid * 1024;
-        char *dw = sbase + BPL * 128 + wid * 1024;
+        char *dw = sbase + BPL * RB + wid * 1024;
         if (UNI) {
             const unsigned tapbit = s_tap < KK ? 1u << s_tap : 0u;
             const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_kb) * 2;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] : OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, soff, 0, 0);
             }
-            s_kb += 64;
+            s_kb += BK;
             if (s_kb >= a.Cin_pad) { s_kb = 0; ++s_tap; if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; } }
         } else {
             int kh = 0, kw = 0;
@@ -187,13 +195,13 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] + delta : OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, 0, 0, 0);
             }
-            v_kc += 64;
+            v_kc += BK;
             while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dw + i * NW * 1024), 16, woff[i], s_wk, 0, 0);
-        s_wk += 128;
+        s_wk += RB;
     };
 
     f32x4 acc[TC][TP];
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = a.Kpad / 64;
+    const int KT = a.Kpad / BK;
     constexpr int D = NS - 1;                  // prefetch distance in K-steps
 #pragma unroll
     for (int t = 0; t < D; ++t)
@@ -212,9 +220,10 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 
     const int l15 = lane & 15, lq = lane >> 4;
     // fragment read offsets inside a stage (two K-halves), constant over the loop
-    const int sw0 = ((0 + lq) ^ (l15 & 7)) << 4, sw1 = ((4 + lq) ^ (l15 & 7)) << 4;
-    const int offx = (wpi * TP * 16 + l15) * 128;
-    const int offw = BPL * 128 + (wci * TC * 16 + l15) * 128;
+    const int sw0 = BK == 64 ? ((0 + lq) ^ (l15 & 7)) << 4 : (lq ^ (3 * ((l15 >> 2) & 1))) << 4;
+    const int sw1 = ((4 + lq) ^ (l15 & 7)) << 4;            // second K-half (BK = 64 only)
+    const int offx = (wpi * TP * 16 + l15) * RB;
+    const int offw = BPL * RB + (wci * TC * 16 + l15) * RB;
     int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
     // DIAG (separate diagnostic instantiation, never the shipped kernel): s_memtime stamps around the phases of a K-step
     unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0;
@@ -234,21 +243,21 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         const unsigned long long s1 = stamp();
         if (kt + D < KT) {
             stage(smem + nxt * STAGE_BYTES);
-            if (WDIRECT) load_wfrag(fnext, (kt + 1) * 128);
+            if (WDIRECT) load_wfrag(fnext, (kt + 1) * RB);
         }
         const unsigned long long s2 = stamp();
         const char *sb = smem + cur * STAGE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             const int sw = kk ? sw1 : sw0;
             bf16x8 fw[TC], fx[TP];
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
                 if (WDIRECT) fw[i] = fcur[i][kk];
-                else fw[i] = *(const bf16x8 *)(sb + offw + i * 2048 + sw);
+                else fw[i] = *(const bf16x8 *)(sb + offw + i * 16 * RB + sw);
             }
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(sb + offx + j * 2048 + sw);
+            for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(sb + offx + j * 16 * RB + sw);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -353,19 +362,29 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 #endif
 }
 
+// dynamic LDS of one instantiation: NS staging buffers, re-used by the epilogue's padded output tile
+template <int WP, int WC, int TP, int TC, int NS, int BK>
+constexpr size_t conv_lds_bytes()
+{
+    constexpr int NW = WP * WC, BP = WP * TP * 16, BC = WC * TC * 16;
+    constexpr int RG = 64 / (BK * 2 / 16);
+    constexpr int LA = ((BP + RG - 1) / RG + NW - 1) / NW, LB = ((BC + RG - 1) / RG + NW - 1) / NW;
+    constexpr size_t stage = (size_t)(LA + LB) * NW * RG * (BK * 2);
+    constexpr size_t lds0 = (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16);
+    return lds0 > ldso ? lds0 : ldso;
+}
+
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
 {
     // diagnostic instantiation of ONE configuration (p176c128_s2, uniform tap)
-    constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2;
+    constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2, BK = 32;
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16, NW = WP * WC;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
-    constexpr int BPL = (BP / 8 + NW - 1) / NW * NW * 8, BCL = (BC / 8 + NW - 1) / NW * NW * 8;
-    constexpr size_t lds0 = (size_t)NS * (BPL + BCL) * 128, ldso = (size_t)BP * (BC * 2 + 16);
-    constexpr size_t lds = lds0 > ldso ? lds0 : ldso;
+    constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     static bool done = false;
-    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -467,25 +486,36 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
-struct CfgDesc { const char *name; int wp, wc, tp, tc, ns; };
-static const CfgDesc kCfgs[] = {
-    {"p128c128_s2", 2, 2, 4, 4, 2}, {"p128c128_s3", 2, 2, 4, 4, 3},
-    {"p64c128_s2", 2, 2, 2, 4, 2},  {"p64c128_s3", 2, 2, 2, 4, 3},
-    {"p256c32_s2", 4, 1, 4, 2, 2},  {"p256c32_s3", 4, 1, 4, 2, 3},
-    {"p128c64_s2", 2, 2, 4, 2, 2},  {"p128c64_s3", 2, 2, 4, 2, 3},
-    {"p256c64_s2", 4, 1, 4, 4, 2},  {"p256c64_s3", 4, 1, 4, 4, 3},
-    {"p256c128_s2", 4, 2, 4, 4, 2}, {"p256c128_s3", 4, 2, 4, 4, 3},
-    {"p128c256_s2", 2, 4, 4, 4, 2}, {"p128c256_s3", 2, 4, 4, 4, 3},
-    {"p64c64_s2", 2, 2, 2, 2, 2},   {"p64c64_s4", 2, 2, 2, 2, 4},
-    {"p256c128_s2b", 4, 2, 4, 4, 2},
-    // pixel-tile heights that are not powers of two: picked by the autotuner when they make the tile count a near
-    // multiple of the 256 CUs x resident workgroups (wave quantisation), e.g. 176 px for M = 32 * 26 * 26
-    {"p176c128_s2", 1, 4, 11, 2, 2}, {"p176c256_s2", 1, 4, 11, 4, 2}, {"p176c64_s2", 1, 4, 11, 1, 2},
-    {"p160c128_s2", 1, 4, 10, 2, 2}, {"p192c128_s2", 1, 4, 12, 2, 2}, {"p144c128_s2", 1, 4, 9, 2, 2},
-    {"p208c128_s2", 1, 4, 13, 2, 2}, {"p96c128_s2", 1, 4, 6, 2, 2},   {"p112c128_s2", 1, 4, 7, 2, 2},
-};
+// Tile configurations: (waves along pixels, waves along channels, 16-px tiles per wave, 16-ch tiles per wave, LDS
+// stages, K-step).  Pixel-tile heights that are not powers of two exist so the autotuner can make the tile count a
+// near multiple of 256 CUs x resident workgroups (wave quantisation), e.g. 176 px for M = 32 * 26 * 26.
+// BK = 32 halves the staging LDS (three or four workgroups per CU) and makes Cin = 32 layers uniform-tap; measured it
+// only pays on the early, short-K layers -- on the deep 3x3 layers the extra barriers cost more than the occupancy
+// buys (0.066 vs 0.053 ms) -- so only a few BK = 32 shapes are kept.
+#define CONV_CFGS(X)                                                                                   \
+    X(0, 2, 2, 4, 4, 2, 64)  X(1, 2, 2, 4, 4, 3, 64)  X(2, 2, 2, 2, 4, 2, 64)  X(3, 2, 2, 2, 4, 3, 64)    \
+    X(4, 4, 1, 4, 2, 2, 64)  X(5, 4, 1, 4, 2, 3, 64)  X(6, 2, 2, 4, 2, 2, 64)  X(7, 2, 2, 4, 2, 3, 64)    \
+    X(8, 4, 1, 4, 4, 2, 64)  X(9, 4, 1, 4, 4, 3, 64)  X(10, 4, 2, 4, 4, 2, 64) X(11, 4, 2, 4, 4, 3, 64)   \
+    X(12, 2, 4, 4, 4, 2, 64) X(13, 2, 4, 4, 4, 3, 64) X(14, 2, 2, 2, 2, 2, 64) X(15, 2, 2, 2, 2, 4, 64)   \
+    X(16, 1, 4, 11, 2, 2, 64) X(17, 1, 4, 11, 4, 2, 64) X(18, 1, 4, 11, 1, 2, 64) X(19, 1, 4, 10, 2, 2, 64) \
+    X(20, 1, 4, 12, 2, 2, 64) X(21, 1, 4, 9, 2, 2, 64) X(22, 1, 4, 13, 2, 2, 64) X(23, 1, 4, 6, 2, 2, 64)  \
+    X(24, 1, 4, 7, 2, 2, 64)                                                                            \
+    X(25, 1, 4, 11, 2, 2, 32) X(26, 2, 2, 4, 2, 2, 32)  X(27, 4, 1, 4, 2, 2, 32)  X(28, 4, 1, 4, 4, 2, 32)  \
+    X(29, 2, 2, 2, 2, 2, 32)  X(30, 2, 2, 2, 4, 2, 32)
+
+struct CfgDesc { int id, wp, wc, tp, tc, ns, bk; };
+#define X(id, wp, wc, tp, tc, ns, bk) {id, wp, wc, tp, tc, ns, bk},
+static const CfgDesc kCfgs[] = {CONV_CFGS(X)};
+#undef X
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
-const char *conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < conv_num_cfgs()) ? kCfgs[cfg].name : "?"; }
+const char *conv_cfg_name(int cfg)
+{
+    static char names[64][32];
+    if (cfg < 0 || cfg >= conv_num_cfgs()) return cfg == CONV_CFG_DIRECT ? "direct_c8" : "?";
+    const CfgDesc &c = kCfgs[cfg];
+    snprintf(names[cfg], sizeof names[cfg], "p%dc%d_s%d_k%d", c.wp * c.tp * 16, c.wc * c.tc * 16, c.ns, c.bk);
+    return names[cfg];
+}
 
 int conv_pick_cfg(const ConvArgs &a)
 {
@@ -498,68 +528,42 @@ int conv_pick_cfg(const ConvArgs &a)
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC, int NS, bool UNI>
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI>
 static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
-    constexpr int NW = WP * WC;
-    constexpr int BPL = (BP / 8 + NW - 1) / NW * NW * 8, BCL = (BC / 8 + NW - 1) / NW * NW * 8;
-    constexpr size_t lds0 = (size_t)NS * (BPL + BCL) * 128, ldso = (size_t)BP * (BC * 2 + 16);
-    constexpr size_t lds = lds0 > ldso ? lds0 : ldso;      // the epilogue's output tile re-uses the staging LDS
+    constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * WP * WC);   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
         static bool done = false;      // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, UNI>,
+            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             done = true;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, UNI>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
-template <int WP, int WC, int TP, int TC, int NS>
+template <int WP, int WC, int TP, int TC, int NS, int BK>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets: the activation window must stay below 2 GiB
     if ((double)a.N * a.H * a.W * a.in_stride * 2.0 + 2.0 * (a.W + 1) * a.in_stride >= 2147483648.0) return hipErrorInvalidValue;
-    return (a.Cin_pad % 64) == 0 ? launch_u<WP, WC, TP, TC, NS, true>(a, s) : launch_u<WP, WC, TP, TC, NS, false>(a, s);
+    return (a.Cin_pad % BK) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, true>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, false>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
     if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
     switch (cfg) {
-    case 0: return launch_t<2, 2, 4, 4, 2>(a, s);
-    case 1: return launch_t<2, 2, 4, 4, 3>(a, s);
-    case 2: return launch_t<2, 2, 2, 4, 2>(a, s);
-    case 3: return launch_t<2, 2, 2, 4, 3>(a, s);
-    case 4: return launch_t<4, 1, 4, 2, 2>(a, s);
-    case 5: return launch_t<4, 1, 4, 2, 3>(a, s);
-    case 6: return launch_t<2, 2, 4, 2, 2>(a, s);
-    case 7: return launch_t<2, 2, 4, 2, 3>(a, s);
-    case 8: return launch_t<4, 1, 4, 4, 2>(a, s);
-    case 9: return launch_t<4, 1, 4, 4, 3>(a, s);
-    case 10: return launch_t<4, 2, 4, 4, 2>(a, s);
-    case 11: return launch_t<4, 2, 4, 4, 3>(a, s);
-    case 12: return launch_t<2, 4, 4, 4, 2>(a, s);
-    case 13: return launch_t<2, 4, 4, 4, 3>(a, s);
-    case 14: return launch_t<2, 2, 2, 2, 2>(a, s);
-    case 15: return launch_t<2, 2, 2, 2, 4>(a, s);
-    case 16: return launch_t<4, 2, 4, 4, 2>(a, s);
-    case 17: return launch_t<1, 4, 11, 2, 2>(a, s);
-    case 18: return launch_t<1, 4, 11, 4, 2>(a, s);
-    case 19: return launch_t<1, 4, 11, 1, 2>(a, s);
-    case 20: return launch_t<1, 4, 10, 2, 2>(a, s);
-    case 21: return launch_t<1, 4, 12, 2, 2>(a, s);
-    case 22: return launch_t<1, 4, 9, 2, 2>(a, s);
-    case 23: return launch_t<1, 4, 13, 2, 2>(a, s);
-    case 24: return launch_t<1, 4, 6, 2, 2>(a, s);
-    case 25: return launch_t<1, 4, 7, 2, 2>(a, s);
+#define X(id, wp, wc, tp, tc, ns, bk) case id: return launch_t<wp, wc, tp, tc, ns, bk>(a, s);
+        CONV_CFGS(X)
+#undef X
     default: return hipErrorInvalidValue;
     }
 }
