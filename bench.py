@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
     args = ap.parse_args()
 
@@ -115,9 +116,13 @@ def main():
                       open(os.path.join(out_dir, os.path.basename(tuned)), "w"))
 
     def step():
-        eng.forward(images, want_detections=False)
-        eng.postprocess(B, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT,
-                        boxes_out=boxes, counts_out=counts)
+        if args.no_graph:
+            eng.forward(images, want_detections=False)
+            eng.postprocess(B, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT,
+                            boxes_out=boxes, counts_out=counts)
+        else:   # same launches, replayed from a HIP graph captured on the second call
+            eng.detect_graph(images, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF,
+                             select_mode=hip.SELECT_GT)
         if G > 1:
             records[:, 0] = counts; records[:, 1:] = boxes
             return ydist.all_gather_detections(records, B * G)

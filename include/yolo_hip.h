@@ -139,6 +139,13 @@ int yolo_detect(yolo_ctx *ctx, const void *images, int n, int fmt, int loc, floa
                 float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
                 yolo_box *boxes_out, int32_t *counts_out, int out_loc);
 
+/* yolo_detect for device-resident inputs and outputs, replayed from a HIP graph: the first call with a given argument
+ * tuple runs eagerly, the second captures the launch sequence (preprocess, ~80 conv/ew launches, decode, NMS) into a
+ * hipGraph, later calls replay it (removes the per-launch gaps of a launch-bound step).  Any change of argument
+ * re-captures.  images / boxes_out / counts_out must be device pointers that stay valid between calls. */
+int yolo_detect_graph(yolo_ctx *ctx, const void *images, int n, int fmt, float scale, float score_thr, float iou_thr,
+                      int max_out, int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out);
+
 int yolo_synchronize(yolo_ctx *ctx);
 
 /* ---- introspection / measurement ------------------------------------------------------------ */

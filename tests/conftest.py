@@ -25,6 +25,14 @@ def has_gpu():
         return False
 
 
+# torch must initialise its HIP context BEFORE libyolo_hip.so makes the first HIP call in this process, otherwise
+# torch.cuda reports no devices on the GPU box; do it once at collection time.
+_TORCH_SEES_GPU = has_gpu()
+if _TORCH_SEES_GPU:
+    import torch
+    torch.cuda.init()
+
+
 @pytest.fixture(scope="session")
 def hiplib():
     """The production library; GPU tests fail (not skip) if it is missing so a silent fallback cannot pass."""

@@ -214,3 +214,75 @@ def test_weights_file_loader(hiplib, tmp_path):
         b = hiplib.Engine(txt); b.load_weights(p, hdr)
         assert np.array_equal(b.forward(img), ref)
         b.close()
+
+
+def test_config2_yolov2_416_fp32_vs_oracle(hiplib):
+    """BASELINE config 2: YOLOv2 416x416 batch 1, fp32 path, Darknet .weights stream through the C ABI -> decoded
+    boxes vs the fp32 oracle (TF semantics).  Tolerance: 2e-4 of the decoded tensor's scale; kept set identical."""
+    txt = IO.cfg_text("yolov2")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0, obj_bias=0.5)
+    img = np.random.default_rng(2).integers(0, 256, (1, 416, 416, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=1, dtype=hiplib.FP32)
+    eng.set_weights(flat)
+    det = eng.forward(img)
+    osecs = R.parse_cfg(txt)
+    heads, _ = R.forward(osecs, R.unflatten_weights(flat, osecs), img.astype(np.float32) / np.float32(255))
+    s, raw = heads[0]
+    bx, ob, cl = R.region_decode(raw, R.yolo_anchors(s), 80)
+    assert det.shape == (1, 845, 85)
+    b = bx.reshape(1, -1, 4)
+    ref = np.concatenate([np.stack([(b[..., 0] + b[..., 2]) / 2, (b[..., 1] + b[..., 3]) / 2, b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]], -1),
+                          ob.reshape(1, -1, 1), cl.reshape(1, -1, 80)], -1)
+    np.testing.assert_allclose(det, ref, rtol=2e-3, atol=2e-4)
+    # V2/postprocess.py tail: score >= 0.5, TF NMS (10, 0.5) -- device vs oracle on the device's own decoded tensor
+    got = eng.postprocess(1, score_thr=0.5, iou_thr=0.5, max_out=10, nms_mode=hiplib.NMS_TF, select_mode=hiplib.SELECT_GE)[0]
+    bb, sc, lb, _ = R.region_select(np.stack([det[0, :, 0] - det[0, :, 2] * np.float32(.5), det[0, :, 1] - det[0, :, 3] * np.float32(.5),
+                                               det[0, :, 0] + det[0, :, 2] * np.float32(.5), det[0, :, 1] + det[0, :, 3] * np.float32(.5)], -1),
+                                    det[0, :, 4], det[0, :, 5:], 0.5)
+    sel = R.tf_nms(bb[:, [1, 0, 3, 2]], sc, 10, 0.5)
+    assert len(got) == len(sel) > 0
+    assert np.array_equal(got["score"], sc[sel]) and np.array_equal(got["cls"], lb[sel])
+    eng.close()
+
+
+def test_config4_yolov3_608_shard_properties(hiplib):
+    """BASELINE config 4 per-GPU shard: YOLOv3 608x608, 8 images (batch 64 over 8 GPUs).  Same size-independent
+    properties as at 416: shape 22743 rows, determinism, batch independence, NMS tail equal to the oracle's."""
+    txt = IO.cfg_text("yolov3-608")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    img = np.random.default_rng(3).integers(0, 256, (8, 608, 608, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=8)
+    eng.set_weights(flat)
+    det = eng.forward(img)
+    assert det.shape == (8, 22743, 85) and np.isfinite(det).all()
+    assert np.array_equal(det, eng.forward(img))
+    assert np.array_equal(eng.forward(img[5:6])[0], det[5])
+    eng.forward(img, want_detections=False)
+    res = eng.postprocess(8, score_thr=0.5, iou_thr=0.5, max_out=20)
+    for b in range(8):
+        ob, os_, oc = R.detect_v3_tf(det[b], 0.5, 0.5, 20)
+        assert np.array_equal(res[b]["score"], os_) and np.array_equal(res[b]["cls"], oc)
+    eng.close()
+
+
+def test_detect_graph_replay_equals_eager(hiplib, v3_416):
+    """The HIP-graph replay of a detect step (third call onwards) returns exactly what eager launches return."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch does not see the GPU in this process")
+    eng, txt, flat, img = v3_416
+    n, max_out = 8, 20
+    d_img = torch.from_numpy(img[:n]).cuda()
+    boxes = torch.zeros((n, max_out * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    eng.forward(d_img, want_detections=False)
+    want = eng.postprocess(n, score_thr=0.5, iou_thr=0.5, max_out=max_out)
+    for it in range(4):                     # eager, capture, replay, replay
+        boxes.zero_(); counts.zero_()
+        eng.detect_graph(d_img, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out)
+        eng.synchronize()
+        got_counts = counts.cpu().numpy(); got = boxes.cpu().numpy().view(hiplib.BOX_DTYPE).reshape(n, max_out)
+        for b in range(n):
+            assert got_counts[b] == len(want[b]) and np.array_equal(got[b, :got_counts[b]], want[b]), "call %d image %d" % (it, b)
+    # a different argument re-captures transparently
+    eng.detect_graph(d_img, boxes, counts, score_thr=0.6, iou_thr=0.5, max_out=max_out)
+    eng.synchronize()

@@ -74,6 +74,9 @@ struct yolo_ctx {
     float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
     void *d_boxes = nullptr; int *d_counts = nullptr; int boxes_cap = 0;
+    // yolo_detect_graph state
+    struct GKey { const void *img; int n, fmt; float scale, st, it; int mo, nm, sm; void *bo, *co; } gkey{};
+    hipGraphExec_t gexec = nullptr; int gstate = 0;      // 0: next call eager, 1: next call captures, 2: replay, -1: capture unsupported
     bool weights_loaded = false;
     int scores_mode = -1;                 // what d_scores/d_labels hold: 0 max(obj*cls) from the decode, 1 objectness, -1 nothing
     size_t weights_count = 0;
@@ -534,6 +537,7 @@ void yolo_destroy(yolo_ctx *c)
     for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -645,6 +649,38 @@ int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float 
 {
     int r = yolo_forward(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE); if (r) return r;
     return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, out_loc);
+}
+
+int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float scale, float score_thr, float iou_thr, int max_out,
+                      int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!images || !boxes_out || !counts_out) return fail(c, YOLO_ERR_INVALID, "yolo_detect_graph needs device pointers for images, boxes_out and counts_out");
+    yolo_ctx::GKey k{images, n, fmt, scale, score_thr, iou_thr, max_out, nms_mode, select_mode, (void *)boxes_out, (void *)counts_out};
+    if (memcmp(&k, &c->gkey, sizeof k) != 0) {
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        c->gkey = k; if (c->gstate >= 0) c->gstate = 0;
+    }
+    auto eager = [&]() -> int {
+        int r = yolo_forward(c, images, n, fmt, YOLO_DEVICE, scale, nullptr, YOLO_DEVICE); if (r) return r;
+        return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, YOLO_DEVICE);
+    };
+    if (c->gstate <= 0) { int r = eager(); if (r == YOLO_OK && c->gstate == 0) c->gstate = 1; return r; }
+    HIPCK(c, hipSetDevice(c->device));
+    if (c->gstate == 1) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); c->gstate = -1; return eager(); }
+        int r = eager();
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (r != YOLO_OK || e != hipSuccess || !g) { (void)hipGetLastError(); if (g) hipGraphDestroy(g); c->gstate = -1; return r ? r : eager(); }
+        e = hipGraphInstantiate(&c->gexec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { (void)hipGetLastError(); c->gexec = nullptr; c->gstate = -1; return eager(); }
+        c->gstate = 2;
+    }
+    HIPCK(c, hipGraphLaunch(c->gexec, c->stream));
+    c->last_n = n; c->scores_mode = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
+    return YOLO_OK;
 }
 
 int yolo_synchronize(yolo_ctx *c) { if (!c) return YOLO_ERR_INVALID; HIPCK(c, hipStreamSynchronize(c->stream)); return YOLO_OK; }

@@ -26,7 +26,7 @@ EXPORTS = [
     "yolo_create", "yolo_destroy", "yolo_last_error", "yolo_load_darknet_weights", "yolo_set_weights",
     "yolo_weights_count", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
-    "yolo_detect", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
+    "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_decode", "yolo_op_postprocess",
 ]
@@ -71,6 +71,7 @@ def load_library():
     l.yolo_forward_image_u8.argtypes = [P, P, I, I, I, P, I]
     l.yolo_postprocess.argtypes = [P, I, F, F, I, I, I, P, P, I]
     l.yolo_detect.argtypes = [P, P, I, I, I, F, F, F, I, I, I, P, P, I]
+    l.yolo_detect_graph.argtypes = [P, P, I, I, F, F, F, I, I, I, P, P]
     l.yolo_layer_output.argtypes = [P, I, I, P, C.c_size_t, C.POINTER(I)]
     l.yolo_time_forward.argtypes = [P, I, I, FP, FP]
     l.yolo_time_layers.argtypes = [P, I, I, FP]
@@ -202,6 +203,16 @@ class Engine:
     def detect(self, images, scale=1.0 / 255.0, **kw):
         self.forward(images, scale=scale, want_detections=False)
         return self.postprocess(int(images.shape[0]), **kw)
+
+    def detect_graph(self, images, boxes_out, counts_out, scale=1.0 / 255.0, score_thr=0.5, iou_thr=0.5, max_out=20,
+                     nms_mode=NMS_TF, select_mode=SELECT_GT):
+        """Device-resident detect replayed from a HIP graph (images / boxes_out / counts_out: device tensors)."""
+        p, loc = _ptr(images); bp, bl = _ptr(boxes_out); cp, cl = _ptr(counts_out)
+        if loc != DEVICE or bl != DEVICE or cl != DEVICE:
+            raise YoloError("detect_graph needs device-resident buffers")
+        fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
+        self._check(self.lib.yolo_detect_graph(self.ctx, p, int(images.shape[0]), fmt, scale, score_thr, iou_thr, max_out,
+                                               nms_mode, select_mode, bp, cp), "yolo_detect_graph")
 
     def synchronize(self):
         self._check(self.lib.yolo_synchronize(self.ctx), "yolo_synchronize")
