@@ -49,12 +49,17 @@ __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "
 
 // UNI: Cin_pad is a multiple of 64, so all 8 chunks of a K-step belong to one tap (scalar tap cursor).
 // otherwise (Cin_pad = 8, 16, 32, ...): the chunks of one K-step span several taps, tap cursor is per lane.
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, bool DIAG = false>
-__global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a)
+// NL > 0: role split -- WP*WC consumer waves only read LDS and issue MFMAs, NL extra loader waves only issue the LDS-DMA
+// (an LDS-DMA instruction blocks the issuing wave for ~66 cycles; in the symmetric NL = 0 form that is time the wave's own
+// MFMAs cannot be issued).  All waves meet at the one s_barrier per K-step.
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false>
+__global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
                                       // kernel whose body uses the buffer-resource builtins with array operands)
-    constexpr int NW = WP * WC;
+    constexpr int NC = WP * WC;                // consumer (MFMA) waves
+    constexpr int NW = NL > 0 ? NL : NC;       // waves that issue the LDS-DMA
+    constexpr int NTOT = NC + NL;              // waves in the workgroup
     constexpr int BP = WP * TP * 16;           // output pixels per workgroup
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
     static_assert(BK == 64 || BK == 32, "K-step");
@@ -79,8 +84,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wpi = wid % WP, wci = wid / WP;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = NL == 0 || wave_id >= NC;          // wave-uniform role
+    const bool is_consumer = wave_id < NC;
+    const int wid = NL > 0 ? (wave_id >= NC ? wave_id - NC : 0) : wave_id;   // index among the loading waves
+    const int wpi = wave_id % WP, wci = (wave_id / WP) % WC;
 
     // XCD-aware tile assignment: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
     // contiguous run of tiles ordered pixel-tile-major so that its resident workgroups re-use the same
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     constexpr int D = NS - 1;                  // prefetch distance in K-steps
 #pragma unroll
     for (int t = 0; t < D; ++t)
-        if (t < KT) stage(smem + t * STAGE_BYTES);
+        if (t < KT && is_loader) stage(smem + t * STAGE_BYTES);
     bf16x8 fwc[TC][2], fwn[TC][2];             // WDIRECT: filter fragments of the current / next K-step
     if (WDIRECT) load_wfrag(fwc, 0);
 
@@ -238,15 +246,16 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     auto kstep = [&](int kt, bf16x8 (&fcur)[TC][2], bf16x8 (&fnext)[TC][2]) {
         const unsigned long long s0 = stamp();
         // K-step kt has landed once at most (D-1) younger K-steps' loads remain outstanding (in-order counter)
-        if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>();
+        if (is_loader) { if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>(); }
         block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
         const unsigned long long s1 = stamp();
-        if (kt + D < KT) {
+        if (kt + D < KT && is_loader) {
             stage(smem + nxt * STAGE_BYTES);
             if (WDIRECT) load_wfrag(fnext, (kt + 1) * RB);
         }
         const unsigned long long s2 = stamp();
         const char *sb = smem + cur * STAGE_BYTES;
+        if (is_consumer)
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             const int sw = kk ? sw1 : sw0;
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         // scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are issue-bound: ~600 cycles each).
         constexpr int RS = BC * 2 + 16;                       // padded LDS row (bytes)
         block_barrier();                                      // every wave is done reading the last stage
+        if (is_consumer)
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
         block_barrier();
         const bf16_t *__restrict__ res = (const bf16_t *)a.res;
         constexpr int CPR = BC / 8;                           // 16-B chunks per tile row
-        constexpr int NT = 64 * NW;
+        constexpr int NT = 64 * NTOT;
         for (int c = tid; c < BP * CPR; c += NT) {
             const int row = c / CPR, cc = c - row * CPR;
             const int m = pt * BP + row, ch = ct * BC + cc * 8;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
             }
             *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
         }
-    } else {
+    } else if (is_consumer) {
         // fp32 output (detection heads, Cout = 255): 4 consecutive channels per lane, 16-B stores
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -356,17 +366,17 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_igemm_bf16(const ConvArgs a
     if (DIAG && a.dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = stamp();
-        unsigned long long *d = a.dbg + ((size_t)tile * NW + wid) * 6;
+        unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 6;
         d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end; d[5] = (unsigned long long)KT;
     }
 #endif
 }
 
 // dynamic LDS of one instantiation: NS staging buffers, re-used by the epilogue's padded output tile
-template <int WP, int WC, int TP, int TC, int NS, int BK>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL = 0>
 constexpr size_t conv_lds_bytes()
 {
-    constexpr int NW = WP * WC, BP = WP * TP * 16, BC = WC * TC * 16;
+    constexpr int NW = NL > 0 ? NL : WP * WC, BP = WP * TP * 16, BC = WC * TC * 16;
     constexpr int RG = 64 / (BK * 2 / 16);
     constexpr int LA = ((BP + RG - 1) / RG + NW - 1) / NW, LB = ((BC + RG - 1) / RG + NW - 1) / NW;
     constexpr size_t stage = (size_t)(LA + LB) * NW * RG * (BK * 2);
@@ -383,8 +393,8 @@ hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     static bool done = false;
-    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, 0, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -493,18 +503,19 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
 // only pays on the early, short-K layers -- on the deep 3x3 layers the extra barriers cost more than the occupancy
 // buys (0.066 vs 0.053 ms) -- so only a few BK = 32 shapes are kept.
 #define CONV_CFGS(X)                                                                                   \
-    X(0, 2, 2, 4, 4, 2, 64)  X(1, 2, 2, 4, 4, 3, 64)  X(2, 2, 2, 2, 4, 2, 64)  X(3, 2, 2, 2, 4, 3, 64)    \
-    X(4, 4, 1, 4, 2, 2, 64)  X(5, 4, 1, 4, 2, 3, 64)  X(6, 2, 2, 4, 2, 2, 64)  X(7, 2, 2, 4, 2, 3, 64)    \
-    X(8, 4, 1, 4, 4, 2, 64)  X(9, 4, 1, 4, 4, 3, 64)  X(10, 4, 2, 4, 4, 2, 64) X(11, 4, 2, 4, 4, 3, 64)   \
-    X(12, 2, 4, 4, 4, 2, 64) X(13, 2, 4, 4, 4, 3, 64) X(14, 2, 2, 2, 2, 2, 64) X(15, 2, 2, 2, 2, 4, 64)   \
-    X(16, 1, 4, 11, 2, 2, 64) X(17, 1, 4, 11, 4, 2, 64) X(18, 1, 4, 11, 1, 2, 64) X(19, 1, 4, 10, 2, 2, 64) \
-    X(20, 1, 4, 12, 2, 2, 64) X(21, 1, 4, 9, 2, 2, 64) X(22, 1, 4, 13, 2, 2, 64) X(23, 1, 4, 6, 2, 2, 64)  \
-    X(24, 1, 4, 7, 2, 2, 64)                                                                            \
-    X(25, 1, 4, 11, 2, 2, 32) X(26, 2, 2, 4, 2, 2, 32)  X(27, 4, 1, 4, 2, 2, 32)  X(28, 4, 1, 4, 4, 2, 32)  \
-    X(29, 2, 2, 2, 2, 2, 32)  X(30, 2, 2, 2, 4, 2, 32)
+    X(0, 2, 2, 4, 4, 2, 64, 0)  X(1, 2, 2, 4, 4, 3, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(3, 2, 2, 2, 4, 3, 64, 0)    \
+    X(4, 4, 1, 4, 2, 2, 64, 0)  X(5, 4, 1, 4, 2, 3, 64, 0)  X(6, 2, 2, 4, 2, 2, 64, 0)  X(7, 2, 2, 4, 2, 3, 64, 0)    \
+    X(8, 4, 1, 4, 4, 2, 64, 0)  X(9, 4, 1, 4, 4, 3, 64, 0)  X(10, 4, 2, 4, 4, 2, 64, 0) X(11, 4, 2, 4, 4, 3, 64, 0)   \
+    X(12, 2, 4, 4, 4, 2, 64, 0) X(13, 2, 4, 4, 4, 3, 64, 0) X(14, 2, 2, 2, 2, 2, 64, 0) X(15, 2, 2, 2, 2, 4, 64, 0)   \
+    X(16, 1, 4, 11, 2, 2, 64, 0) X(17, 1, 4, 11, 4, 2, 64, 0) X(18, 1, 4, 11, 1, 2, 64, 0) X(19, 1, 4, 10, 2, 2, 64, 0) \
+    X(20, 1, 4, 12, 2, 2, 64, 0) X(21, 1, 4, 9, 2, 2, 64, 0) X(22, 1, 4, 13, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0)  \
+    X(24, 1, 4, 7, 2, 2, 64, 0)                                                                            \
+    X(25, 1, 4, 11, 2, 2, 32, 0) X(26, 2, 2, 4, 2, 2, 32, 0)  X(27, 4, 1, 4, 2, 2, 32, 0)  X(28, 4, 1, 4, 4, 2, 32, 0)  \
+    X(29, 2, 2, 2, 2, 2, 32, 0)  X(30, 2, 2, 2, 4, 2, 32, 0)                                                \
+    X(31, 1, 8, 11, 2, 2, 64, 4)
 
-struct CfgDesc { int id, wp, wc, tp, tc, ns, bk; };
-#define X(id, wp, wc, tp, tc, ns, bk) {id, wp, wc, tp, tc, ns, bk},
+struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl; };
+#define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl},
 static const CfgDesc kCfgs[] = {CONV_CFGS(X)};
 #undef X
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
@@ -513,7 +524,7 @@ const char *conv_cfg_name(int cfg)
     static char names[64][32];
     if (cfg < 0 || cfg >= conv_num_cfgs()) return cfg == CONV_CFG_DIRECT ? "direct_c8" : "?";
     const CfgDesc &c = kCfgs[cfg];
-    snprintf(names[cfg], sizeof names[cfg], "p%dc%d_s%d_k%d", c.wp * c.tp * 16, c.wc * c.tc * 16, c.ns, c.bk);
+    snprintf(names[cfg], sizeof names[cfg], "p%dc%d_s%d_k%d%s%d", c.wp * c.tp * 16, c.wc * c.tc * 16, c.ns, c.bk, c.nl ? "_L" : "_w", c.nl ? c.nl : c.wp * c.wc);
     return names[cfg];
 }
 
@@ -528,40 +539,40 @@ int conv_pick_cfg(const ConvArgs &a)
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI>
 static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
-    constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
-    dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * WP * WC);   // multiple of 8: see the XCD mapping
+    constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL>();
+    dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * (WP * WC + NL));   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
         static bool done = false;      // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI>,
+            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI, NL>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             done = true;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI, NL>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets: the activation window must stay below 2 GiB
     if ((double)a.N * a.H * a.W * a.in_stride * 2.0 + 2.0 * (a.W + 1) * a.in_stride >= 2147483648.0) return hipErrorInvalidValue;
-    return (a.Cin_pad % BK) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, true>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, false>(a, s);
+    return (a.Cin_pad % BK) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
     if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
     switch (cfg) {
-#define X(id, wp, wc, tp, tc, ns, bk) case id: return launch_t<wp, wc, tp, tc, ns, bk>(a, s);
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl>(a, s);
         CONV_CFGS(X)
 #undef X
     default: return hipErrorInvalidValue;
