@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
         return t;
     };
-    if (DIAG) t_all0 = stamp();
+    unsigned long long rt0 = 0;
+    if (DIAG) { t_all0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // one K-step; `fcur` / `fnext` are the filter-fragment register sets of this and the next step (WDIRECT only: the
     // loop is unrolled by two so the sets ping-pong without a copy, which would force an early wait on the loads)
     auto kstep = [&](int kt, bf16x8 (&fcur)[TC][2], bf16x8 (&fnext)[TC][2]) {
@@ -367,7 +368,9 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = stamp();
         unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 6;
-        d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end; d[5] = (unsigned long long)KT;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end;
+        d[5] = ((unsigned long long)KT << 40) | ((t_end - t_all0) * 100ull / (rt1 - rt0 ? rt1 - rt0 : 1));   // KT | shader MHz (realtime = 100 MHz)
     }
 #endif
 }
@@ -387,7 +390,7 @@ constexpr size_t conv_lds_bytes()
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
 {
     // diagnostic instantiation of ONE configuration (p176c128_s2, uniform tap)
-    constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2, BK = 32;
+    constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2, BK = 64;
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16, NW = WP * WC;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);

@@ -859,13 +859,14 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build, printed to stderr
         const long tiles = (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
         a.dbg = (unsigned long long *)S.alloc((size_t)tiles * 4 * 6 * 8);
-        for (int rep = 0; rep < 3; ++rep) e = launch_conv_diag(a, S.s);
+        for (int rep = 0; rep < 200; ++rep) e = launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
         std::vector<unsigned long long> hd((size_t)tiles * 4 * 6);
         S.download(hd.data(), a.dbg, hd.size() * 8);
-        double w = 0, is = 0, mm = 0, lp = 0, ep = 0; size_t cnt = hd.size() / 6;
-        for (size_t i = 0; i < cnt; ++i) { w += hd[i * 6]; is += hd[i * 6 + 1]; mm += hd[i * 6 + 2]; lp += hd[i * 6 + 3]; ep += hd[i * 6 + 4]; }
-        fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles\n",
-                cnt, hd[5], w / cnt / hd[5], is / cnt / hd[5], mm / cnt / hd[5], lp / cnt / hd[5], ep / cnt);
+        double w = 0, is = 0, mm = 0, lp = 0, ep = 0, mhz = 0; size_t cnt = hd.size() / 6;
+        const unsigned long long kt = hd[5] >> 40;
+        for (size_t i = 0; i < cnt; ++i) { w += hd[i * 6]; is += hd[i * 6 + 1]; mm += hd[i * 6 + 2]; lp += hd[i * 6 + 3]; ep += hd[i * 6 + 4]; mhz += (double)(hd[i * 6 + 5] & 0xffffffffffull); }
+        fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz\n",
+                cnt, kt, w / cnt / kt, is / cnt / kt, mm / cnt / kt, lp / cnt / kt, ep / cnt, mhz / cnt);
     } else
         e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
     if (!S.ok(e)) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
