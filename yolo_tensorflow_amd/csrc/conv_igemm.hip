@@ -515,7 +515,7 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
     X(24, 1, 4, 7, 2, 2, 64, 0)                                                                            \
     X(25, 1, 4, 11, 2, 2, 32, 0) X(26, 2, 2, 4, 2, 2, 32, 0)  X(27, 4, 1, 4, 2, 2, 32, 0)  X(28, 4, 1, 4, 4, 2, 32, 0)  \
     X(29, 2, 2, 2, 2, 2, 32, 0)  X(30, 2, 2, 2, 4, 2, 32, 0)                                                \
-    X(31, 1, 8, 11, 2, 2, 64, 4)
+    X(31, 1, 8, 11, 2, 2, 64, 4) X(32, 1, 8, 11, 2, 2, 64, 0)
 
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl},
