@@ -176,8 +176,10 @@ int yolo_op_conv_num_cfgs(void);
 int yolo_op_upsample2x(const float *x, int n, int h, int w, int c, int semantics, float *out, int device);
 int yolo_op_reorg(const float *x, int n, int h, int w, int c, int stride, int semantics, float *out, int device);
 int yolo_op_maxpool(const float *x, int n, int h, int w, int c, int size, int stride, float *out, int device);
-/* legacy-bilinear stretch of one uint8 image to [s,s,3] fp32 (value/255 then resize). */
-int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float *out, int device);
+/* legacy-bilinear stretch of one uint8 image to [s,s,3] fp32: (value/255 then resize) * post_scale. */
+int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float post_scale, float *out, int device);
+/* `detections_boxes` (V3/yolo_v3.py:329-347): (cx,cy,w,h,...) -> (x0,y0,x1,y1,...) over [n,rows,attrs] fp32 */
+int yolo_op_detections_boxes(const float *det, int n, int rows, int attrs, float *out, int device);
 /* head decode of raw [n,g,g,na*(5+classes)] fp32: yolo (logistic) or region (softmax) */
 int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const float *anchors_wh,
                    int img_size, int decode, int region, float *out, int device);

@@ -95,3 +95,37 @@ def test_detector_classes(hiplib):
             assert len(ws) == len(scores)
             np.testing.assert_allclose(scores, ws, rtol=1e-3, atol=1e-4)
         d.engine.close()
+
+
+def test_yolo_v2_entry_points(hiplib):
+    """V2 demo chain (V2/Main.py): preprocess_image -> build_network -> decode (3 outputs) -> postprocess, and the
+    `postprocess.decode` TF-NMS form, each stage against the oracle on the device's own previous-stage output."""
+    from yolo_tensorflow_amd import yolo_v2
+    size = 160
+    txt = IO.with_input_size(IO.cfg_text("yolov2"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 5)
+    m = yolo_v2.Model(size=size, max_batch=1, dtype=hiplib.FP32, weights=flat)
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    x = yolo_v2.preprocess_image(img, (size, size))
+    want_x = R.resize_bilinear_legacy(img.astype(np.float32) / np.float32(255), size, size) * np.float32(255.0 / 225.0)
+    np.testing.assert_allclose(x[0], want_x, rtol=0, atol=2e-6)
+    out = yolo_v2.build_network(x, model=m)
+    g = size // 32
+    assert out.shape == (1, g * g * 5, 85)
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    heads, _ = R.forward(osecs, params, x)
+    rb, ro, rc = R.region_decode(heads[0][1], np.array(yolo_v2.anchors, np.float32), 80)
+    bboxes, obj, cls = yolo_v2.decode(out, output_sizes=(g, g), num_class=80)
+    assert bboxes.shape == (1, g * g, 5, 4) and obj.shape == (1, g * g, 5) and cls.shape == (1, g * g, 5, 80)
+    np.testing.assert_allclose(bboxes, rb, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(obj, ro, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(cls, rc, rtol=2e-3, atol=2e-3)
+    c = R.detections_boxes(out).reshape(1, g * g, 5, 85)
+    assert np.array_equal(bboxes, c[..., :4]) and np.array_equal(obj, c[..., 4]) and np.array_equal(cls, c[..., 5:])
+    thr = float(np.quantile((obj[..., None] * cls).max(-1), 0.9))
+    b, s, k = yolo_v2.postprocess(bboxes, obj, cls, image_shape=img.shape[:2], threshold=thr)
+    wb, ws, wk = R.v2_postprocess(bboxes, obj, cls, img.shape[:2], thr)
+    assert len(ws) > 0
+    assert np.array_equal(b, wb) and np.array_equal(s, ws) and np.array_equal(k, wk)
+    m.close()

@@ -78,7 +78,7 @@ hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scal
 
 // legacy TF bilinear (no half-pixel offset): src = dst * (in/out); value/255 first (D2T _input_process)
 template <typename T>
-__global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, int out_stride, int out_c)
+__global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, int out_stride, int out_c, float post_scale)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= so * so) return;
@@ -98,6 +98,7 @@ __global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, in
         float top = tl + (tr - tl) * xl;
         float bot = bl + (br - bl) * xl;
         v[c] = top + (bot - top) * yl;
+        if (post_scale != 1.0f) v[c] *= post_scale;
     }
     if (out_c >= 8) Elt<T>::store8(out + (size_t)p * out_stride, v);
     else
@@ -105,11 +106,11 @@ __global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, in
 }
 
 hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32, int out_stride,
-                            int out_c, hipStream_t s)
+                            int out_c, hipStream_t s, float post_scale)
 {
     size_t np = (size_t)s_out * s_out;
-    if (out_f32) hipLaunchKernelGGL(k_resize_u8<float>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (float *)out, out_stride, out_c);
-    else hipLaunchKernelGGL(k_resize_u8<bf16_t>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (bf16_t *)out, out_stride, out_c);
+    if (out_f32) hipLaunchKernelGGL(k_resize_u8<float>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (float *)out, out_stride, out_c, post_scale);
+    else hipLaunchKernelGGL(k_resize_u8<bf16_t>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (bf16_t *)out, out_stride, out_c, post_scale);
     return hipGetLastError();
 }
 

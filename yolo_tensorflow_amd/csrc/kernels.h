@@ -63,7 +63,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 hipError_t launch_preprocess(const void *img, int fmt /*0 u8, 1 f32*/, int n, int hw, float scale,
                              void *out, int out_f32, int out_stride, hipStream_t s);
 hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32,
-                            int out_stride, int out_c, hipStream_t s);
+                            int out_stride, int out_c, hipStream_t s, float post_scale = 1.0f);
 hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s);
 hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s);
 hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s);
@@ -98,3 +98,4 @@ struct PostArgs {
     void *boxes_out; int *counts_out;   // yolo_box [n*max_out], int [n] (device)
 };
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);
+hipError_t launch_boxes_to_corners(const float *in, float *out, size_t nrows, int attrs, hipStream_t s);

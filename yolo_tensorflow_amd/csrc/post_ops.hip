@@ -423,3 +423,25 @@ hipError_t launch_postprocess(const PostArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_nms_image, dim3(a.n), dim3(NMS_THREADS), 0, s, a);
     return hipGetLastError();
 }
+
+// ---- X: `detections_boxes` (V3/yolo_v3.py:329-347): (cx, cy, w, h, rest...) -> (x0, y0, x1, y1, rest...), w/2 form ----
+__global__ void k_boxes_to_corners(const float *in, float *out, size_t nrows, int attrs)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * attrs) return;
+    size_t r = idx / attrs; int k = (int)(idx - r * attrs);
+    const float *p = in + r * attrs;
+    float v;
+    if (k == 0) v = p[0] - p[2] / 2.0f;
+    else if (k == 1) v = p[1] - p[3] / 2.0f;
+    else if (k == 2) v = p[0] + p[2] / 2.0f;
+    else if (k == 3) v = p[1] + p[3] / 2.0f;
+    else v = p[k];
+    out[idx] = v;
+}
+hipError_t launch_boxes_to_corners(const float *in, float *out, size_t nrows, int attrs, hipStream_t s)
+{
+    size_t total = nrows * attrs;
+    hipLaunchKernelGGL(k_boxes_to_corners, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, nrows, attrs);
+    return hipGetLastError();
+}

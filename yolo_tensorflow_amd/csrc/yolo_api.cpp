@@ -901,13 +901,13 @@ int yolo_op_upsample2x(const float *x, int n, int h, int w, int c, int semantics
 int yolo_op_reorg(const float *x, int n, int h, int w, int c, int stride, int semantics, float *out, int device) { return ew_op(1, x, n, h, w, c, stride, semantics, 0, out, device); }
 int yolo_op_maxpool(const float *x, int n, int h, int w, int c, int size, int stride, float *out, int device) { return ew_op(2, x, n, h, w, c, size, stride, 0, out, device); }
 
-int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float *out, int device)
+int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float post_scale, float *out, int device)
 {
     if (!img || !out || h < 1 || w < 1 || s < 1) return YOLO_ERR_INVALID;
     OpScope S(device); if (S.rc) return S.rc;
     uint8_t *d_i = (uint8_t *)S.upload(img, (size_t)h * w * 3); float *d_o = (float *)S.alloc((size_t)s * s * 3 * 4);
     if (S.rc) return S.rc;
-    if (!S.ok(launch_resize_u8(d_i, h, w, s, d_o, 1, 3, 3, S.s))) { g_op_err = S.err; return S.rc; }
+    if (!S.ok(launch_resize_u8(d_i, h, w, s, d_o, 1, 3, 3, S.s, post_scale))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, (size_t)s * s * 3 * 4);
 }
 
@@ -925,6 +925,17 @@ int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const fl
     for (int k = 0; k < 2 * na; ++k) d.anchors[k] = region ? anchors_wh[k] : (float)(1.0 * (double)anchors_wh[k] / (double)stride);
     d.det = d_o; d.rows_total = g * g * na; d.row_off = 0;
     if (!S.ok(launch_decode(d, nullptr, nullptr, S.s))) { g_op_err = S.err; return S.rc; }
+    return S.download(out, d_o, cnt * 4);
+}
+
+int yolo_op_detections_boxes(const float *det, int n, int rows, int attrs, float *out, int device)
+{
+    if (!det || !out || n < 1 || rows < 1 || attrs < 5) return YOLO_ERR_INVALID;
+    OpScope S(device); if (S.rc) return S.rc;
+    const size_t cnt = (size_t)n * rows * attrs;
+    float *d_i = (float *)S.upload(det, cnt * 4), *d_o = (float *)S.alloc(cnt * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_boxes_to_corners(d_i, d_o, (size_t)n * rows, attrs, S.s))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, cnt * 4);
 }
 

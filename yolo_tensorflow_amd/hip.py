@@ -28,7 +28,7 @@ EXPORTS = [
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
-    "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_decode", "yolo_op_postprocess",
+    "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_decode", "yolo_op_postprocess",
 ]
 
 
@@ -83,7 +83,8 @@ def load_library():
     l.yolo_op_upsample2x.argtypes = [P, I, I, I, I, I, P, I]
     l.yolo_op_reorg.argtypes = [P, I, I, I, I, I, I, P, I]
     l.yolo_op_maxpool.argtypes = [P, I, I, I, I, I, I, P, I]
-    l.yolo_op_resize_u8.argtypes = [P, I, I, I, P, I]
+    l.yolo_op_resize_u8.argtypes = [P, I, I, I, F, P, I]
+    l.yolo_op_detections_boxes.argtypes = [P, I, I, I, P, I]
     l.yolo_op_decode.argtypes = [P, I, I, I, I, P, I, I, I, P, I]
     l.yolo_op_postprocess.argtypes = [P, I, I, I, F, F, I, I, I, P, P, I]
     _lib = l
@@ -303,10 +304,17 @@ def op_maxpool(x, size=2, stride=2, device=0):
     return out
 
 
-def op_resize_u8(img, size, device=0):
+def op_resize_u8(img, size, post_scale=1.0, device=0):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     out = np.empty((size, size, 3), dtype=np.float32)
-    _op_check(load_library().yolo_op_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], size, out.ctypes.data, device), "yolo_op_resize_u8")
+    _op_check(load_library().yolo_op_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], size, post_scale, out.ctypes.data, device), "yolo_op_resize_u8")
+    return out
+
+
+def op_detections_boxes(det, device=0):
+    det = _f32(det); n, rows, attrs = det.shape
+    out = np.empty_like(det)
+    _op_check(load_library().yolo_op_detections_boxes(det.ctypes.data, n, rows, attrs, out.ctypes.data, device), "yolo_op_detections_boxes")
     return out
 
 

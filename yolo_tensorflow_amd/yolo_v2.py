@@ -28,8 +28,8 @@ def preprocess_image(image, image_size=(416, 416)):
     device and returns [1,H,W,3] float32.  NB the reference divides by 225.0 (a typo, :22); reproduced."""
     if image_size[0] != image_size[1]:
         raise hip.YoloError("square network input only")
-    x = hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0])      # value/255 then resize
-    return (x * np.float32(255.0 / 225.0))[None]
+    # (value/255 -> legacy bilinear) * 255/225 on the device == resize(value)/225 up to rounding
+    return hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0], post_scale=255.0 / 225.0)[None]
 
 
 def build_network(images, num_outputs=425, alpha=0.1, keep_prob=0.5, is_training=False, scope='yolov2', model=None):
@@ -50,12 +50,9 @@ def decode(model_output, output_sizes=(13, 13), num_class=80, threshold=None, io
     n = d.shape[0]
     H, W = output_sizes
     A = d.shape[1] // (H * W)
-    d4 = d.reshape(n, H * W, A, 5 + num_class)
-    two = np.float32(2)
-    bboxes = np.stack([d4[..., 0] - d4[..., 2] / two, d4[..., 1] - d4[..., 3] / two,
-                       d4[..., 0] + d4[..., 2] / two, d4[..., 1] + d4[..., 3] / two], axis=3)
     if threshold is None:
-        return bboxes, d4[..., 4], d4[..., 5:]
+        c4 = hip.op_detections_boxes(d).reshape(n, H * W, A, 5 + num_class)      # bbox_x - bbox_w/2 ... on the device
+        return np.ascontiguousarray(c4[..., 0:4]), np.ascontiguousarray(c4[..., 4]), np.ascontiguousarray(c4[..., 5:])
     res = hip.op_postprocess(d, threshold, iou_threshold, 10, hip.NMS_TF, hip.SELECT_GE)
     r = res[0] if n == 1 else res
     if n == 1:

@@ -112,11 +112,11 @@ def load_weights(var_list, weights_file, size=416, num_classes=80, max_batch=32,
 
 
 def detections_boxes(detections):
-    """V3/yolo_v3.py:329: (cx, cy, w, h, ...) -> (x0, y0, x1, y1, ...).  Pure layout arithmetic on the returned
-    host array (the device computes the same corners inside yolo_postprocess)."""
-    d = np.asarray(detections, dtype=np.float32)
-    w2 = d[..., 2:3] / np.float32(2); h2 = d[..., 3:4] / np.float32(2)
-    return np.concatenate([d[..., 0:1] - w2, d[..., 1:2] - h2, d[..., 0:1] + w2, d[..., 1:2] + h2, d[..., 4:]], axis=-1)
+    """V3/yolo_v3.py:329: (cx, cy, w, h, ...) -> (x0, y0, x1, y1, ...), on the device (k_boxes_to_corners)."""
+    d = np.ascontiguousarray(detections, dtype=np.float32)
+    squeeze = d.ndim == 2
+    out = hip.op_detections_boxes(d[None] if squeeze else d)
+    return out[0] if squeeze else out
 
 
 def non_max_suppression(predictions_with_boxes, confidence_threshold, iou_threshold=0.4, device=0):
