@@ -297,6 +297,23 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         // residual loads) are 16 B per lane along the channel axis -- whole 128-B lines per pixel instead of 16
         // scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are issue-bound: ~600 cycles each).
         constexpr int RS = BC * 2 + 16;                       // padded LDS row (bytes)
+        constexpr int CPR = BC / 8;                           // 16-B chunks per tile row
+        constexpr int NT = 64 * NTOT;
+        constexpr int NIT = (BP * CPR + NT - 1) / NT;         // 16-B pieces of the output tile per thread
+        // residual (shortcut source) pieces are fetched now, all at once, so that their latency is covered by the
+        // accumulator -> LDS pass below instead of being paid once per piece in the store loop
+        const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+        uint4 rpre[NIT];
+        if (res) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = tid + it * NT;
+                const int row = c / CPR, cc = c - row * CPR;
+                const int m = pt * BP + row, ch = ct * BC + cc * 8;
+                rpre[it] = (c < BP * CPR && m < M && ch < a.Cout) ? *(const uint4 *)(res + (size_t)m * a.res_stride + ch)
+                                                                  : uint4{0, 0, 0, 0};
+            }
+        }
         block_barrier();                                      // every wave is done reading the last stage
         if (is_consumer)
 #pragma unroll
@@ -318,18 +335,17 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();
-        const bf16_t *__restrict__ res = (const bf16_t *)a.res;
-        constexpr int CPR = BC / 8;                           // 16-B chunks per tile row
-        constexpr int NT = 64 * NTOT;
-        for (int c = tid; c < BP * CPR; c += NT) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * NT;
             const int row = c / CPR, cc = c - row * CPR;
             const int m = pt * BP + row, ch = ct * BC + cc * 8;
-            if (!full && (m >= M || ch >= a.Cout)) continue;
+            if (c >= BP * CPR || (!full && (m >= M || ch >= a.Cout))) continue;
             uint4 o = *(const uint4 *)(smem + row * RS + cc * 16);
             if (res) {
                 // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
                 // by a separate shortcut kernel; the sum is rounded once more
-                const uint4 r = *(const uint4 *)(res + (size_t)m * a.res_stride + ch);
+                const uint4 r = rpre[it];
                 uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
