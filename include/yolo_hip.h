@@ -43,7 +43,9 @@ enum yolo_status {
     YOLO_ERR_UNSUPPORTED = -6
 };
 
-enum yolo_dtype { YOLO_BF16 = 0, YOLO_FP32 = 1 };          /* storage/compute type of the conv stack */
+/* storage/compute type of the conv stack.  YOLO_FP8 (BASELINE config 5): OCP e4m3 filters and activations on the
+ * fp8 MFMA (fp32 accumulation, heads in fp32, first conv in bf16); scheme and scales: DESIGN.md "fp8 scheme". */
+enum yolo_dtype { YOLO_BF16 = 0, YOLO_FP32 = 1, YOLO_FP8 = 2 };
 enum yolo_semantics { YOLO_SEM_TF = 0, YOLO_SEM_DARKNET = 1 };
 /* TF: bilinear `_upsample` (V3/yolo_v3.py:162-192) + tf.space_to_depth (V2/model_darknet19_slim.py:44);
  * DARKNET: nearest upsample (DN/blas.c:334) + reorg_cpu (DN/blas.c:9) -- lets the whole network be
@@ -104,6 +106,11 @@ int yolo_load_darknet_weights(yolo_ctx *ctx, const char *path, int header_ints);
 /* Same from the float stream that follows the header (n floats, must match the topology). */
 int yolo_set_weights(yolo_ctx *ctx, const float *flat, size_t n);
 size_t yolo_weights_count(const yolo_ctx *ctx);
+/* YOLO_FP8 only: per-layer activation scales (stored code = e4m3(value / scale)), one float per cfg layer; entries of
+ * layers that only move data (route, upsample, maxpool, reorg, yolo/region) are ignored.  Default: all 1.  Call BEFORE
+ * loading weights (filters absorb their input scales; a later call invalidates loaded weights).  No reference
+ * counterpart: the reference has no reduced-precision path. */
+int yolo_set_act_scales(yolo_ctx *ctx, const float *scales, int n_layers);
 
 /* ---- geometry ------------------------------------------------------------------------------- */
 int yolo_input_size(const yolo_ctx *ctx, int *height, int *width, int *channels);

@@ -40,6 +40,114 @@ def to_bf16(x):
     return np.where(np.isnan(x), x, out)
 
 
+def to_fp8_e4m3(x):
+    """Round float32 -> OCP e4m3 (e4m3fn: 4 exponent bits, bias 7, 3 mantissa bits, no infinities, max 448),
+    round-to-nearest-even, saturating at +-448, returned as float32 values on the e4m3 grid.  Emulates the
+    device's fp8 storage (BASELINE config 5); not part of the reference, which has no reduced-precision path."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    a = np.minimum(np.abs(x), np.float32(448.0))
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, np.float32(1.0)))).astype(np.int32)
+    # log2 of a float32 just below a power of two can round up: fix with an exact comparison
+    e = np.where(np.ldexp(np.float32(1.0), e) > a, e - 1, e)
+    e = np.maximum(e, -6)                                  # subnormals share the quantum of the first binade (2^-9)
+    quantum = np.ldexp(np.float32(1.0), e - 3).astype(np.float32)
+    q = np.rint(a / quantum).astype(np.float32)            # np.rint rounds half to even; a / quantum is exact
+    out = np.copysign(q * quantum, x).astype(np.float32)
+    return np.where(np.isnan(x), x, out)
+
+
+def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=None):
+    """Emulation of the device's fp8 configuration (yolo_tensorflow_amd/csrc, DESIGN.md "fp8 scheme") in numpy:
+      * every stored activation is an e4m3 code with a per-layer scale (value = code * scale; `scales[i]`, default 1);
+        data-movement layers inherit their input's scale; the image and the first conv's filters are bf16;
+      * conv i > 0: filters (BN folded) are multiplied by the scale of each input channel, then quantised per output
+        channel c to e4m3 with osc[c] = max|w| / 448; acc = sum(code_w * code_x) in fp32; v = acc * osc[c] + bias;
+        leaky; v rounded to bf16 (the device stages the tile through LDS in bf16); head convs keep v in fp32;
+      * stored code = e4m3(v * (1 / scale)); shortcut = e4m3((a * s_a + b * s_b) * (1 / s_out)).
+    x: [N,S,S,3] float32 in 0..1.  Returns (heads, outs) like forward(); outs hold real values (code * scale).
+    teacher: optional per-layer list of real-valued tensors (the device's own layer outputs).  Where given, layer i's
+    result is still computed and returned, but the layers after it consume teacher[i] instead -- every layer is then
+    checked on identical inputs, so one-ulp rounding flips cannot compound through the depth of the network."""
+    f32 = np.float32
+    layers = secs[1:]
+    NL = len(layers)
+    user = np.ones(NL, np.float32) if scales is None else np.asarray(scales, np.float32)
+    codes = [None] * NL; chs = [None] * NL       # e4m3 code values, per-channel scale vectors
+    outs, heads = [], []
+    x = to_bf16(np.asarray(x, dtype=np.float32))
+    ci = 0
+    for i, s in enumerate(layers):
+        t = s["type"]
+        if t == "convolutional":
+            p = params[ci]; ci += 1
+            st = int(s.get("stride", 1))
+            is_head = i + 1 < NL and layers[i + 1]["type"] in ("yolo", "region")
+            w, b = fold_bn(p)
+            if i == 0:
+                y = conv2d_nhwc(x, to_bf16(w), st) + b
+            else:
+                cx, sx = codes[i - 1], chs[i - 1]
+                weff = (w * sx[None, None, :, None]).astype(np.float32)             # HWIO
+                amax = np.abs(weff).max(axis=(0, 1, 2))
+                osc = np.where(amax > 0, amax / f32(448.0), f32(1.0)).astype(np.float32)
+                wq = to_fp8_e4m3(weff / osc[None, None, None, :])
+                acc = conv2d_nhwc(cx, wq, st)
+                y = (acc.astype(np.float64) * osc.astype(np.float64) + b.astype(np.float64)).astype(np.float32)   # device: one fma
+            act = s.get("activation", "logistic")
+            if act == "leaky":
+                y = leaky_relu(y)
+            elif act != "linear":
+                raise ValueError(act)
+            y = y.astype(np.float32)
+            if is_head:
+                outs.append(y); continue
+            inv = f32(1.0) / user[i]
+            codes[i] = to_fp8_e4m3(to_bf16(y) * inv); chs[i] = np.full(codes[i].shape[-1], user[i], np.float32)
+        elif t == "shortcut":
+            f = int(s["from"]); f = f if f >= 0 else i + f
+            sa, sb = chs[i - 1][0], chs[f][0]
+            inv = f32(1.0) / user[i]
+            codes[i] = to_fp8_e4m3(((codes[i - 1] * sa).astype(np.float32) + (codes[f] * sb).astype(np.float32)).astype(np.float32) * inv)
+            chs[i] = np.full(codes[i].shape[-1], user[i], np.float32)
+        elif t == "route":
+            ls = [int(v) for v in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            codes[i] = np.concatenate([codes[l] for l in ls], axis=-1) if len(ls) > 1 else codes[ls[0]]
+            chs[i] = np.concatenate([chs[l] for l in ls]) if len(ls) > 1 else chs[ls[0]]
+        elif t == "upsample":
+            codes[i] = to_fp8_e4m3(upsample_tf(codes[i - 1])) if semantics == "tf" else upsample_nearest(codes[i - 1], int(s.get("stride", 2)))
+            chs[i] = chs[i - 1]
+        elif t == "maxpool":
+            st = int(s.get("stride", 1)); k = int(s.get("size", st))
+            codes[i] = max_pool(codes[i - 1], k, st, int(s.get("padding", (k - 1) // 2))); chs[i] = chs[i - 1]
+        elif t == "reorg":
+            st = int(s.get("stride", 1))
+            codes[i] = space_to_depth(codes[i - 1], st) if semantics == "tf" else reorg_darknet(codes[i - 1], st)
+            chs[i] = np.full(codes[i].shape[-1], chs[i - 1][0], np.float32)
+        elif t in ("yolo", "region"):
+            heads.append((s, outs[i - 1])); outs.append(None); continue
+        else:
+            raise ValueError(t)
+        outs.append((codes[i] * chs[i]).astype(np.float32))
+        if teacher is not None and teacher[i] is not None and not (t == "route" and len(ls) > 1):
+            codes[i] = to_fp8_e4m3(np.asarray(teacher[i], np.float32) / chs[i])
+    return heads, outs
+
+
+def fp8_calibrate_scales(secs, outs_fp32, headroom=2.0):
+    """Per-layer power-of-two activation scales from a full-precision run's per-layer outputs (forward(collect=True)):
+    the largest |value| of conv / shortcut outputs maps to at most 448 / headroom.  Other layers get 1 (ignored)."""
+    layers = secs[1:]
+    sc = np.ones(len(layers), np.float32)
+    for i, s in enumerate(layers):
+        if s["type"] in ("convolutional", "shortcut") and outs_fp32[i] is not None:
+            m = float(np.abs(outs_fp32[i]).max())
+            if m > 0:
+                sc[i] = np.float32(2.0 ** np.ceil(np.log2(m * headroom / 448.0)))
+    return sc
+
+
 def sigmoid(x):
     x = np.asarray(x, dtype=np.float32)
     return (np.float32(1) / (np.float32(1) + np.exp(-x, dtype=np.float32))).astype(np.float32)

@@ -131,3 +131,23 @@ def test_fold_bn_equals_unfused():
     x = rng.normal(size=(1, 8, 8, 4)).astype(np.float32)
     w, b = R.fold_bn(p)
     np.testing.assert_allclose(R.conv2d_nhwc(x, w) + b, R.batch_norm(R.conv2d_nhwc(x, p["w_hwio"]), p, "tf"), rtol=1e-4, atol=1e-5)
+
+
+def test_to_fp8_e4m3_grid_ties_and_saturation():
+    """The e4m3 rounding used to emulate the device's fp8 storage: every representable value is a fixed point, exact
+    midpoints go to the even code, |x| > 448 saturates, the subnormal quantum is 2^-9."""
+    vals = []
+    for code in range(127):                                   # 0x7f is NaN
+        e, m = (code >> 3) & 15, code & 7
+        vals.append((m / 8.0) * 2.0 ** -6 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7))
+    vals = np.array(vals, np.float32)                          # code order == value order
+    assert vals.max() == 448.0 and vals[1] == 2.0 ** -9
+    assert np.array_equal(R.to_fp8_e4m3(vals), vals) and np.array_equal(R.to_fp8_e4m3(-vals), -vals)
+    mid = (vals[:-1] + vals[1:]) / 2
+    want = np.where(np.arange(len(mid)) % 2 == 0, vals[:-1], vals[1:])
+    assert np.array_equal(R.to_fp8_e4m3(mid), want)
+    assert np.array_equal(R.to_fp8_e4m3(np.array([1e9, -500.0, 460.0], np.float32)), np.array([448.0, -448.0, 448.0], np.float32))
+    x = np.random.default_rng(0).normal(0, 30, 20000).astype(np.float32)
+    q = R.to_fp8_e4m3(x)
+    nearest = vals[np.abs(np.abs(x)[:, None].clip(max=448) - vals[None, :]).argmin(1)]
+    assert np.all(np.abs(np.abs(q) - np.abs(x).clip(max=448)) <= np.abs(nearest - np.abs(x).clip(max=448)) + 1e-12)

@@ -27,6 +27,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
@@ -35,6 +36,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
     return (uint32_t)__builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+// two floats -> two OCP e4m3 codes (RNE, saturating at +-448) merged into the low / high half of `old`
+template <bool HI> __device__ __forceinline__ uint32_t f32x2_to_fp8(float a, float b, uint32_t old)
+{
+    a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX); b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HI);
+}
 
 __device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t shift)
 {
@@ -52,8 +59,11 @@ __device__ __forceinline__ void block_barrier() { asm volatile("s_barrier" ::: "
 // NL > 0: role split -- WP*WC consumer waves only read LDS and issue MFMAs, NL extra loader waves only issue the LDS-DMA
 // (an LDS-DMA instruction blocks the issuing wave for ~66 cycles; in the symmetric NL = 0 form that is time the wave's own
 // MFMAs cannot be issued).  All waves meet at the one s_barrier per K-step.
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false>
-__global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const ConvArgs a)
+// EB: bytes per input element -- 2: bf16 operands (v_mfma_f32_16x16x32_bf16), 1: OCP e4m3 operands
+// (v_mfma_f32_16x16x128_f8f6f4, twice the bf16 rate).  The byte geometry of the LDS tiles is the same for both: a
+// 128-B row is 64 bf16 or 128 fp8 of K, so the fp8 form walks K twice as fast with the same loads.
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2>
+__global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
                                       // kernel whose body uses the buffer-resource builtins with array operands)
@@ -63,7 +73,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
     constexpr int BP = WP * TP * 16;           // output pixels per workgroup
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
     static_assert(BK == 64 || BK == 32, "K-step");
+    static_assert(EB == 2 || (EB == 1 && BK == 64), "fp8 operands need the 128-B-row form");
     constexpr int RB = BK * 2;                 // bytes of one LDS tile row (one K-step of one pixel / filter)
+    constexpr int EPC = 16 / EB;               // elements per 16-B chunk
+    constexpr int BKE = RB / EB;               // K elements per step
     constexpr int CPRW = RB / 16;              // 16-B chunks per row: 8 or 4
     constexpr int RG = 64 / CPRW;              // rows filled by one wave-level LDS-DMA instruction: 8 or 16
     constexpr int GP = (BP + RG - 1) / RG, GC = (BC + RG - 1) / RG;
@@ -104,8 +117,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
 
     // Buffer descriptors.  The activation base is moved back by (W+1) pixels so that the offset of tap (0,0) of a
     // border pixel (one row up, one column left) is still >= 0.
-    const int shift = (a.W + 1) * a.in_stride;                       // elements
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const bf16_t *)a.in - shift), 0, BUF_RECORDS, 0x00020000);
+    const int shift = (a.W + 1) * a.in_stride * EB;                  // bytes
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.in - shift), 0, BUF_RECORDS, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.wt, 0, BUF_RECORDS, 0x00020000);
 
     // ---- per-lane constants: wave w fills row groups w, w+NW, ...; inside a group lane l fills LDS slot
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
             const int oy = fast_div(rem, a.wo_mul, a.wo_shift);
             const int ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride + (UNI ? chunk * 8 : 0)) * 2u;
+            off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride + (UNI ? chunk * EPC : 0)) * (unsigned)EB;
             if (a.ksize == 3) {
                 unsigned ry = 0, cx = 0;
 #pragma unroll
@@ -157,12 +170,12 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int crow = (wid + i * NW) * RG + rl;
-        woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * 8) * 2u : OOB_OFFSET;
+        woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * EPC) * (unsigned)EB : OOB_OFFSET;
     }
 
     // K cursor.  UNI: scalars (tap, kh, kw, channel base).  Otherwise per lane (chunk-dependent).
     int s_tap = 0, s_kh = 0, s_kw = 0, s_kb = 0;        // UNI
-    int v_kc = chunk * 8, v_tap = 0;                    // !UNI
+    int v_kc = chunk * EPC, v_tap = 0;                  // !UNI
     if (!UNI)
         while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
     int s_wk = 0;                                       // byte offset of the K-step in a filter row
@@ -184,26 +197,26 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         char *dw = sbase + BPL * RB + wid * 1024;
         if (UNI) {
             const unsigned tapbit = s_tap < KK ? 1u << s_tap : 0u;
-            const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_kb) * 2;
+            const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_kb) * EB;
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] : OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, soff, 0, 0);
             }
-            s_kb += BK;
+            s_kb += BKE;
             if (s_kb >= a.Cin_pad) { s_kb = 0; ++s_tap; if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; } }
         } else {
             int kh = 0, kw = 0;
             if (a.ksize == 3) { kh = (v_tap * 11) >> 5; kw = v_tap - kh * 3; }
             else if (a.ksize != 1) { kh = v_tap / a.ksize; kw = v_tap - kh * a.ksize; }
             const unsigned tapbit = v_tap < KK ? 1u << v_tap : 0u;
-            const unsigned delta = (unsigned)((kh * a.W + kw) * a.in_stride + v_kc) * 2u;
+            const unsigned delta = (unsigned)((kh * a.W + kw) * a.in_stride + v_kc) * (unsigned)EB;
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] + delta : OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, 0, 0, 0);
             }
-            v_kc += BK;
+            v_kc += BKE;
             while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
         }
 #pragma unroll
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = a.Kpad / BK;
+    const int KT = a.Kpad / BKE;
     constexpr int D = NS - 1;                  // prefetch distance in K-steps
 #pragma unroll
     for (int t = 0; t < D; ++t)
@@ -256,7 +269,28 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         }
         const unsigned long long s2 = stamp();
         const char *sb = smem + cur * STAGE_BYTES;
-        if (is_consumer)
+        if (EB == 1) {
+            // e4m3: one K = 128 MFMA per tile pair.  Lane (l15, lq) supplies bytes [32*lq, 32*lq + 32) of its row
+            // for BOTH operands (chunks 2*lq and 2*lq+1 behind the same XOR swizzle), so the pairing of K indices
+            // inside the instruction is consistent whatever its internal order (tools/probe/mfma_fp8.hip).
+            if (is_consumer) {
+                const int swa = ((2 * lq) ^ (l15 & 7)) << 4, swb = ((2 * lq + 1) ^ (l15 & 7)) << 4;
+                i32x8 fw[TC], fx[TP];
+                auto frag = [&](const char *row) -> i32x8 {
+                    const uint4 lo = *(const uint4 *)(row + swa), hi = *(const uint4 *)(row + swb);
+                    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                };
+#pragma unroll
+                for (int i = 0; i < TC; ++i) fw[i] = frag(sb + offw + i * 16 * RB);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) fx[j] = frag(sb + offx + j * 16 * RB);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fx[j], acc[i][j], 0, 0, 0, 0, 0, 0);
+            }
+        } else if (is_consumer)
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             const int sw = kk ? sw1 : sw0;
@@ -292,26 +326,39 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
 
     // ---- epilogue ----
     const bool full = (pt * BP + BP <= M) && (ct * BC + BC <= a.Cout);     // no ragged edge in this tile
-    if (!a.out_f32) {
-        // bf16 output: bias + activation in registers, then the tile goes through LDS so that global stores (and the
-        // residual loads) are 16 B per lane along the channel axis -- whole 128-B lines per pixel instead of 16
-        // scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are issue-bound: ~600 cycles each).
+    if (a.out_dt != DT_F32) {
+        // bf16 / fp8 output: scale + bias + activation in registers, then the tile goes through LDS (as bf16) so that
+        // global stores (and the residual loads) are 16 B per lane along the channel axis -- whole 128-B lines per
+        // pixel instead of 16 scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are
+        // issue-bound: ~600 cycles each).  A 16-B piece is 8 bf16 or 16 fp8 channels.
         constexpr int RS = BC * 2 + 16;                       // padded LDS row (bytes)
-        constexpr int CPR = BC / 8;                           // 16-B chunks per tile row
         constexpr int NT = 64 * NTOT;
-        constexpr int NIT = (BP * CPR + NT - 1) / NT;         // 16-B pieces of the output tile per thread
+        constexpr int CPR = BC / 8, NIT = (BP * CPR + NT - 1) / NT;       // bf16 pieces per row / per thread
+        constexpr int CPR8 = BC / 16, NIT8 = (BP * CPR8 + NT - 1) / NT;   // fp8 pieces
+        const bool out8 = a.out_dt == DT_FP8;
         // residual (shortcut source) pieces are fetched now, all at once, so that their latency is covered by the
         // accumulator -> LDS pass below instead of being paid once per piece in the store loop
-        const bf16_t *__restrict__ res = (const bf16_t *)a.res;
+        const char *__restrict__ res = (const char *)a.res;
         uint4 rpre[NIT];
         if (res) {
+            if (out8) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = tid + it * NT;
-                const int row = c / CPR, cc = c - row * CPR;
-                const int m = pt * BP + row, ch = ct * BC + cc * 8;
-                rpre[it] = (c < BP * CPR && m < M && ch < a.Cout) ? *(const uint4 *)(res + (size_t)m * a.res_stride + ch)
-                                                                  : uint4{0, 0, 0, 0};
+                for (int it = 0; it < NIT8; ++it) {
+                    const int c = tid + it * NT;
+                    const int row = c / CPR8, cc = c - row * CPR8;
+                    const int m = pt * BP + row, ch = ct * BC + cc * 16;
+                    rpre[it] = (c < BP * CPR8 && m < M && ch < a.Cout) ? *(const uint4 *)(res + (size_t)m * a.res_stride + ch)
+                                                                       : uint4{0, 0, 0, 0};
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int c = tid + it * NT;
+                    const int row = c / CPR, cc = c - row * CPR;
+                    const int m = pt * BP + row, ch = ct * BC + cc * 8;
+                    rpre[it] = (c < BP * CPR && m < M && ch < a.Cout) ? *(const uint4 *)(res + ((size_t)m * a.res_stride + ch) * 2)
+                                                                      : uint4{0, 0, 0, 0};
+                }
             }
         }
         block_barrier();                                      // every wave is done reading the last stage
@@ -320,9 +367,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         for (int i = 0; i < TC; ++i) {
             const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
             const float4 bv = *(const float4 *)(a.bias + ct * BC + chl);
+            float4 sv = float4{1.f, 1.f, 1.f, 1.f};
+            if (EB == 1 && a.oscale) sv = *(const float4 *)(a.oscale + ct * BC + chl);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+                float v[4];
+                if (EB == 1) { v[0] = acc[i][j][0] * sv.x + bv.x; v[1] = acc[i][j][1] * sv.y + bv.y; v[2] = acc[i][j][2] * sv.z + bv.z; v[3] = acc[i][j][3] * sv.w + bv.w; }
+                else { v[0] = acc[i][j][0] + bv.x; v[1] = acc[i][j][1] + bv.y; v[2] = acc[i][j][2] + bv.z; v[3] = acc[i][j][3] + bv.w; }
                 if (a.act == ACT_LEAKY) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
@@ -335,27 +386,64 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();
+        if (out8) {
+            // e4m3 output: the bf16-rounded value times 1/scale, RNE, saturating (shortcut: see below)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c = tid + it * NT;
-            const int row = c / CPR, cc = c - row * CPR;
-            const int m = pt * BP + row, ch = ct * BC + cc * 8;
-            if (c >= BP * CPR || (!full && (m >= M || ch >= a.Cout))) continue;
-            uint4 o = *(const uint4 *)(smem + row * RS + cc * 16);
-            if (res) {
-                // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
-                // by a separate shortcut kernel; the sum is rounded once more
-                const uint4 r = rpre[it];
-                uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+            for (int it = 0; it < NIT8; ++it) {
+                const int c = tid + it * NT;
+                const int row = c / CPR8, cc = c - row * CPR8;
+                const int m = pt * BP + row, ch = ct * BC + cc * 16;
+                if (c >= BP * CPR8 || (!full && (m >= M || ch >= a.Cout))) continue;
+                const uint4 o0 = *(const uint4 *)(smem + row * RS + cc * 32), o1 = *(const uint4 *)(smem + row * RS + cc * 32 + 16);
+                const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                float v[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = bf16_bits_to_f32(ov[q] & 0xffff) + bf16_bits_to_f32(rv[q] & 0xffff);
-                    const float hi = bf16_bits_to_f32(ov[q] >> 16) + bf16_bits_to_f32(rv[q] >> 16);
-                    ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
+                for (int q = 0; q < 8; ++q) { v[2 * q] = bf16_bits_to_f32(ow[q] & 0xffff); v[2 * q + 1] = bf16_bits_to_f32(ow[q] >> 16); }
+                if (res) {
+                    // as if the shortcut ran as its own kernel (ew_ops k_add): this conv's output is first quantised
+                    // with its own scale, then (x * s_x + r * s_r) is formed with separately rounded operations
+                    const uint4 r = rpre[it];
+                    const int rw[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int xw = (int)f32x2_to_fp8<true>(v[4 * q + 2] * a.mid_inv_scale, v[4 * q + 3] * a.mid_inv_scale,
+                                                               f32x2_to_fp8<false>(v[4 * q] * a.mid_inv_scale, v[4 * q + 1] * a.mid_inv_scale, 0));
+                        v[4 * q + 0] = __fadd_rn(__fmul_rn(__builtin_amdgcn_cvt_f32_fp8(xw, 0), a.mid_scale), __fmul_rn(__builtin_amdgcn_cvt_f32_fp8(rw[q], 0), a.res_scale));
+                        v[4 * q + 1] = __fadd_rn(__fmul_rn(__builtin_amdgcn_cvt_f32_fp8(xw, 1), a.mid_scale), __fmul_rn(__builtin_amdgcn_cvt_f32_fp8(rw[q], 1), a.res_scale));
+                        v[4 * q + 2] = __fadd_rn(__fmul_rn(__builtin_amdgcn_cvt_f32_fp8(xw, 2), a.mid_scale), __fmul_rn(__builtin_amdgcn_cvt_f32_fp8(rw[q], 2), a.res_scale));
+                        v[4 * q + 3] = __fadd_rn(__fmul_rn(__builtin_amdgcn_cvt_f32_fp8(xw, 3), a.mid_scale), __fmul_rn(__builtin_amdgcn_cvt_f32_fp8(rw[q], 3), a.res_scale));
+                    }
                 }
-                o = uint4{ov[0], ov[1], ov[2], ov[3]};
+                uint32_t pw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pw[q] = f32x2_to_fp8<true>(v[4 * q + 2] * a.out_inv_scale, v[4 * q + 3] * a.out_inv_scale,
+                                               f32x2_to_fp8<false>(v[4 * q] * a.out_inv_scale, v[4 * q + 1] * a.out_inv_scale, 0));
+                *(uint4 *)((char *)a.out + (size_t)m * a.out_stride + ch) = uint4{pw[0], pw[1], pw[2], pw[3]};
             }
-            *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = tid + it * NT;
+                const int row = c / CPR, cc = c - row * CPR;
+                const int m = pt * BP + row, ch = ct * BC + cc * 8;
+                if (c >= BP * CPR || (!full && (m >= M || ch >= a.Cout))) continue;
+                uint4 o = *(const uint4 *)(smem + row * RS + cc * 16);
+                if (res) {
+                    // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
+                    // by a separate shortcut kernel; the sum is rounded once more
+                    const uint4 r = rpre[it];
+                    uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(ov[q] & 0xffff) + bf16_bits_to_f32(rv[q] & 0xffff);
+                        const float hi = bf16_bits_to_f32(ov[q] >> 16) + bf16_bits_to_f32(rv[q] >> 16);
+                        ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
+                    }
+                    o = uint4{ov[0], ov[1], ov[2], ov[3]};
+                }
+                *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
+            }
         }
     } else if (is_consumer) {
         // fp32 output (detection heads, Cout = 255): 4 consecutive channels per lane, 16-B stores
@@ -364,11 +452,15 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm_bf16(const Con
             const int ch = ct * BC + (wci * TC + i) * 16 + lq * 4;
             if (ch >= a.Cout) continue;
             const float4 bv = *(const float4 *)(a.bias + ch);
+            float4 sv = float4{1.f, 1.f, 1.f, 1.f};
+            if (EB == 1 && a.oscale) sv = *(const float4 *)(a.oscale + ch);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const int m = pt * BP + (wpi * TP + j) * 16 + l15;
                 if (m >= M) continue;
-                float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+                float v[4];
+                if (EB == 1) { v[0] = acc[i][j][0] * sv.x + bv.x; v[1] = acc[i][j][1] * sv.y + bv.y; v[2] = acc[i][j][2] * sv.z + bv.z; v[3] = acc[i][j][3] * sv.w + bv.w; }
+                else { v[0] = acc[i][j][0] + bv.x; v[1] = acc[i][j][1] + bv.y; v[2] = acc[i][j][2] + bv.z; v[3] = acc[i][j][3] + bv.w; }
                 if (a.act == ACT_LEAKY) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
@@ -412,8 +504,8 @@ hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     static bool done = false;
-    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, true, 0, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -488,7 +580,14 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
                     uint2 pk;
                     pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
                     pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
-                    *(uint2 *)((bf16_t *)a.out + (size_t)mrow[u] * a.out_stride + i * 16 + lq * 4) = pk;
+                    if (a.out_dt == DT_FP8) {
+                        // same value chain as the tiled kernel: bf16 rounding, then e4m3 of value / scale_out
+                        const float s8 = a.out_inv_scale;
+                        const uint32_t w8 = f32x2_to_fp8<true>(bf16_bits_to_f32(pk.y & 0xffff) * s8, bf16_bits_to_f32(pk.y >> 16) * s8,
+                                                               f32x2_to_fp8<false>(bf16_bits_to_f32(pk.x & 0xffff) * s8, bf16_bits_to_f32(pk.x >> 16) * s8, 0));
+                        *(uint32_t *)((char *)a.out + (size_t)mrow[u] * a.out_stride + i * 16 + lq * 4) = w8;
+                    } else
+                        *(uint2 *)((bf16_t *)a.out + (size_t)mrow[u] * a.out_stride + i * 16 + lq * 4) = pk;
                 }
             }
         }
@@ -498,7 +597,7 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
 
 bool conv_c8_direct_ok(const ConvArgs &a)
 {
-    return a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin_pad == 8 && !a.out_f32 && !a.res && a.Kpad >= 96 &&
+    return a.in_dt == DT_BF16 && a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin_pad == 8 && a.out_dt != DT_F32 && !a.res && a.Kpad >= 96 &&
            (a.Cout == 16 || a.Cout == 32 || a.Cout == 64);
 }
 
@@ -558,7 +657,7 @@ int conv_pick_cfg(const ConvArgs &a)
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI, int EB>
 static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
@@ -569,30 +668,59 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
     if (lds > 65536) {
         static bool done = false;      // per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI, NL>,
+            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             done = true;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_bf16<WP, WC, TP, TC, NS, BK, UNI, NL>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, int EB>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets: the activation window must stay below 2 GiB
-    if ((double)a.N * a.H * a.W * a.in_stride * 2.0 + 2.0 * (a.W + 1) * a.in_stride >= 2147483648.0) return hipErrorInvalidValue;
-    return (a.Cin_pad % BK) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false>(a, s);
+    if (((double)a.N * a.H * a.W * a.in_stride + 2.0 * (a.W + 1) * a.in_stride) * EB >= 2147483648.0) return hipErrorInvalidValue;
+    constexpr int BKE = BK * 2 / EB;
+    if (a.Kpad % BKE) return hipErrorInvalidValue;
+    return (a.Cin_pad % BKE) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true, EB>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false, EB>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
+    if (a.in_dt != DT_BF16) return hipErrorInvalidValue;
     if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
     switch (cfg) {
-#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl>(a, s);
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2>(a, s);
         CONV_CFGS(X)
+#undef X
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// fp8 operands: the same tile ids, restricted to the two-stage 128-B-row symmetric shapes that the bf16 tuning kept
+#define CONV_CFGS_FP8(X)                                                                                     \
+    X(0, 2, 2, 4, 4, 2, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(4, 4, 1, 4, 2, 2, 64, 0)  X(6, 2, 2, 4, 2, 2, 64, 0)    \
+    X(8, 4, 1, 4, 4, 2, 64, 0)  X(12, 2, 4, 4, 4, 2, 64, 0) X(14, 2, 2, 2, 2, 2, 64, 0) X(16, 1, 4, 11, 2, 2, 64, 0)  \
+    X(17, 1, 4, 11, 4, 2, 64, 0) X(19, 1, 4, 10, 2, 2, 64, 0) X(20, 1, 4, 12, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0) \
+    X(32, 1, 8, 11, 2, 2, 64, 0)
+bool conv_cfg_fp8_ok(int cfg)
+{
+    switch (cfg) {
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return true;
+        CONV_CFGS_FP8(X)
+#undef X
+    default: return false;
+    }
+}
+hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s)
+{
+    if (a.in_dt != DT_FP8) return hipErrorInvalidValue;
+    switch (cfg) {
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 1>(a, s);
+        CONV_CFGS_FP8(X)
 #undef X
     default: return hipErrorInvalidValue;
     }

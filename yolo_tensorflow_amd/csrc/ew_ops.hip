@@ -48,6 +48,39 @@ template <> struct Elt<float> {
     static __device__ __forceinline__ void store1(float *p, float f) { *p = f; }
 };
 
+template <> struct Elt<fp8_t> {      // OCP e4m3: decode is exact, encode is round-to-nearest-even with saturation at +-448
+    template <bool HI> static __device__ __forceinline__ uint32_t enc2(float a, float b, uint32_t old)
+    {
+        a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX); b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);
+        return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HI);
+    }
+    static __device__ __forceinline__ void load8(const fp8_t *p, float *v)
+    {
+        uint2 u = *(const uint2 *)p;
+        v[0] = __builtin_amdgcn_cvt_f32_fp8((int)u.x, 0); v[1] = __builtin_amdgcn_cvt_f32_fp8((int)u.x, 1);
+        v[2] = __builtin_amdgcn_cvt_f32_fp8((int)u.x, 2); v[3] = __builtin_amdgcn_cvt_f32_fp8((int)u.x, 3);
+        v[4] = __builtin_amdgcn_cvt_f32_fp8((int)u.y, 0); v[5] = __builtin_amdgcn_cvt_f32_fp8((int)u.y, 1);
+        v[6] = __builtin_amdgcn_cvt_f32_fp8((int)u.y, 2); v[7] = __builtin_amdgcn_cvt_f32_fp8((int)u.y, 3);
+    }
+    static __device__ __forceinline__ void store8(fp8_t *p, const float *v)
+    {
+        uint2 u;
+        u.x = enc2<true>(v[2], v[3], enc2<false>(v[0], v[1], 0));
+        u.y = enc2<true>(v[6], v[7], enc2<false>(v[4], v[5], 0));
+        *(uint2 *)p = u;
+    }
+    static __device__ __forceinline__ float load1(const fp8_t *p) { return __builtin_amdgcn_cvt_f32_fp8((int)p->b, 0); }
+    static __device__ __forceinline__ void store1(fp8_t *p, float f) { p->b = (uint8_t)(enc2<false>(f, 0.f, 0) & 0xff); }
+};
+
+// run `stmt` with T bound to the element type of `dt`
+#define WITH_DT(dt, ...)                                                         \
+    do {                                                                         \
+        if ((dt) == DT_F32) { typedef float T; __VA_ARGS__; }                    \
+        else if ((dt) == DT_FP8) { typedef fp8_t T; __VA_ARGS__; }               \
+        else { typedef bf16_t T; __VA_ARGS__; }                                  \
+    } while (0)
+
 static inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 // ---- row P: uint8/float image at network size -> 8-channel (3 real + 5 zero) activation ---------
@@ -67,12 +100,11 @@ __global__ void k_preprocess(const void *img, int fmt, size_t npix, float scale,
     Elt<T>::store8(out + p * out_stride, v);
 }
 
-hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scale, void *out, int out_f32,
+hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scale, void *out, int out_dt,
                              int out_stride, hipStream_t s)
 {
     size_t npix = (size_t)n * hw;
-    if (out_f32) hipLaunchKernelGGL(k_preprocess<float>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (float *)out, out_stride);
-    else hipLaunchKernelGGL(k_preprocess<bf16_t>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (bf16_t *)out, out_stride);
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_preprocess<T>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (T *)out, out_stride));
     return hipGetLastError();
 }
 
@@ -105,12 +137,11 @@ __global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, in
         for (int c = 0; c < out_c; ++c) Elt<T>::store1(out + (size_t)p * out_stride + c, v[c]);
 }
 
-hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32, int out_stride,
+hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_dt, int out_stride,
                             int out_c, hipStream_t s, float post_scale)
 {
     size_t np = (size_t)s_out * s_out;
-    if (out_f32) hipLaunchKernelGGL(k_resize_u8<float>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (float *)out, out_stride, out_c, post_scale);
-    else hipLaunchKernelGGL(k_resize_u8<bf16_t>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (bf16_t *)out, out_stride, out_c, post_scale);
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_resize_u8<T>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (T *)out, out_stride, out_c, post_scale));
     return hipGetLastError();
 }
 
@@ -151,8 +182,7 @@ __global__ void k_upsample2x(const T *in, int is, T *out, int os, int n, int h, 
 hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s)
 {
     size_t total = (size_t)in.n * 4 * in.h * in.w * (in.c / 8);
-    if (in.f32) hipLaunchKernelGGL(k_upsample2x<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, bilinear);
-    else hipLaunchKernelGGL(k_upsample2x<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, bilinear);
+    WITH_DT(in.dt, hipLaunchKernelGGL(k_upsample2x<T>, grid_for(total), dim3(256), 0, s, (const T *)in.ptr, in.stride, (T *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, bilinear));
     return hipGetLastError();
 }
 
@@ -186,8 +216,7 @@ __global__ void k_maxpool(const T *in, int is, T *out, int os, int n, int h, int
 hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s)
 {
     size_t total = (size_t)out.n * out.h * out.w * (in.c / 8);
-    if (in.f32) hipLaunchKernelGGL(k_maxpool<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, out.h, out.w, in.c / 8, size, stride, pad);
-    else hipLaunchKernelGGL(k_maxpool<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, out.h, out.w, in.c / 8, size, stride, pad);
+    WITH_DT(in.dt, hipLaunchKernelGGL(k_maxpool<T>, grid_for(total), dim3(256), 0, s, (const T *)in.ptr, in.stride, (T *)out.ptr, out.stride, in.n, in.h, in.w, out.h, out.w, in.c / 8, size, stride, pad));
     return hipGetLastError();
 }
 
@@ -235,19 +264,17 @@ hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darkn
 {
     if (!darknet) {
         size_t total = (size_t)in.n * in.h * in.w * (in.c / 8);
-        if (in.f32) hipLaunchKernelGGL(k_space_to_depth<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, stride);
-        else hipLaunchKernelGGL(k_space_to_depth<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, stride);
+        WITH_DT(in.dt, hipLaunchKernelGGL(k_space_to_depth<T>, grid_for(total), dim3(256), 0, s, (const T *)in.ptr, in.stride, (T *)out.ptr, out.stride, in.n, in.h, in.w, in.c / 8, stride));
     } else {
         size_t total = (size_t)in.n * in.h * in.w * in.c;
-        if (in.f32) hipLaunchKernelGGL(k_reorg_darknet<float>, grid_for(total), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, in.n, in.h, in.w, in.c, stride);
-        else hipLaunchKernelGGL(k_reorg_darknet<bf16_t>, grid_for(total), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, in.n, in.h, in.w, in.c, stride);
+        WITH_DT(in.dt, hipLaunchKernelGGL(k_reorg_darknet<T>, grid_for(total), dim3(256), 0, s, (const T *)in.ptr, in.stride, (T *)out.ptr, out.stride, in.n, in.h, in.w, in.c, stride));
     }
     return hipGetLastError();
 }
 
 // ---- rows B / Rt fallbacks: residual add and strided copy --------------------------------------
 template <typename T>
-__global__ void k_add(const T *a, int as, const T *b, int bs, T *o, int os, size_t npix, int c8)
+__global__ void k_add(const T *a, int as, const T *b, int bs, T *o, int os, size_t npix, int c8, float sa, float sb, float so)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c8) return;
@@ -256,14 +283,13 @@ __global__ void k_add(const T *a, int as, const T *b, int bs, T *o, int os, size
     Elt<T>::load8(a + p * as + g * 8, x);
     Elt<T>::load8(b + p * bs + g * 8, y);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] += y[i];
+    for (int i = 0; i < 8; ++i) x[i] = (x[i] * sa + y[i] * sb) * so;       // scales are exactly 1 unless fp8
     Elt<T>::store8(o + p * os + g * 8, x);
 }
-hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s)
+hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s, float sa, float sb, float so)
 {
     size_t npix = (size_t)a.n * a.h * a.w; int c8 = a.c / 8;
-    if (a.f32) hipLaunchKernelGGL(k_add<float>, grid_for(npix * c8), dim3(256), 0, s, (const float *)a.ptr, a.stride, (const float *)b.ptr, b.stride, (float *)out.ptr, out.stride, npix, c8);
-    else hipLaunchKernelGGL(k_add<bf16_t>, grid_for(npix * c8), dim3(256), 0, s, (const bf16_t *)a.ptr, a.stride, (const bf16_t *)b.ptr, b.stride, (bf16_t *)out.ptr, out.stride, npix, c8);
+    WITH_DT(a.dt, hipLaunchKernelGGL(k_add<T>, grid_for(npix * c8), dim3(256), 0, s, (const T *)a.ptr, a.stride, (const T *)b.ptr, b.stride, (T *)out.ptr, out.stride, npix, c8, sa, sb, so));
     return hipGetLastError();
 }
 
@@ -280,40 +306,37 @@ __global__ void k_copy(const T *a, int as, T *o, int os, size_t npix, int c8)
 hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s)
 {
     size_t npix = (size_t)in.n * in.h * in.w; int c8 = in.c / 8;
-    if (in.f32) hipLaunchKernelGGL(k_copy<float>, grid_for(npix * c8), dim3(256), 0, s, (const float *)in.ptr, in.stride, (float *)out.ptr, out.stride, npix, c8);
-    else hipLaunchKernelGGL(k_copy<bf16_t>, grid_for(npix * c8), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, (bf16_t *)out.ptr, out.stride, npix, c8);
+    WITH_DT(in.dt, hipLaunchKernelGGL(k_copy<T>, grid_for(npix * c8), dim3(256), 0, s, (const T *)in.ptr, in.stride, (T *)out.ptr, out.stride, npix, c8));
     return hipGetLastError();
 }
 
 // ---- dtype conversion between dense fp32 NHWC host-staging buffers and device views -------------
 template <typename T>
-__global__ void k_to_f32(const T *in, int is, float *out, size_t npix, int c)
+__global__ void k_to_f32(const T *in, int is, float *out, size_t npix, int c, float scale)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c) return;
     size_t p = idx / c; int ch = (int)(idx - p * c);
-    out[idx] = Elt<T>::load1(in + p * is + ch);
+    out[idx] = Elt<T>::load1(in + p * is + ch) * scale;
 }
-hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s)
+hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s, float scale)
 {
     size_t npix = (size_t)in.n * in.h * in.w;
-    if (in.f32) hipLaunchKernelGGL(k_to_f32<float>, grid_for(npix * in.c), dim3(256), 0, s, (const float *)in.ptr, in.stride, out, npix, in.c);
-    else hipLaunchKernelGGL(k_to_f32<bf16_t>, grid_for(npix * in.c), dim3(256), 0, s, (const bf16_t *)in.ptr, in.stride, out, npix, in.c);
+    WITH_DT(in.dt, hipLaunchKernelGGL(k_to_f32<T>, grid_for(npix * in.c), dim3(256), 0, s, (const T *)in.ptr, in.stride, out, npix, in.c, scale));
     return hipGetLastError();
 }
 
 template <typename T>
-__global__ void k_from_f32(const float *in, T *out, int os, size_t npix, int c)
+__global__ void k_from_f32(const float *in, T *out, int os, size_t npix, int c, float scale)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c) return;
     size_t p = idx / c; int ch = (int)(idx - p * c);
-    Elt<T>::store1(out + p * os + ch, in[idx]);
+    Elt<T>::store1(out + p * os + ch, in[idx] * scale);
 }
-hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s)
+hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, float scale)
 {
     size_t npix = (size_t)out.n * out.h * out.w;
-    if (out.f32) hipLaunchKernelGGL(k_from_f32<float>, grid_for(npix * out.c), dim3(256), 0, s, in, (float *)out.ptr, out.stride, npix, out.c);
-    else hipLaunchKernelGGL(k_from_f32<bf16_t>, grid_for(npix * out.c), dim3(256), 0, s, in, (bf16_t *)out.ptr, out.stride, npix, out.c);
+    WITH_DT(out.dt, hipLaunchKernelGGL(k_from_f32<T>, grid_for(npix * out.c), dim3(256), 0, s, in, (T *)out.ptr, out.stride, npix, out.c, scale));
     return hipGetLastError();
 }

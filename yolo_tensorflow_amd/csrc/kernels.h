@@ -4,6 +4,10 @@
 #include <stdint.h>
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
+struct fp8_t { uint8_t b; };   // raw OCP e4m3 (e4m3fn) bits in HBM
+enum { DT_BF16 = 0, DT_F32 = 1, DT_FP8 = 2 };
+inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_FP8 ? 1 : 2; }
+#define FP8_MAX 448.0f
 
 // A view of an NHWC activation tensor living inside a (possibly wider) buffer: pixel p, channel c is
 // at ptr[p * stride + c].  Concats are never materialised: producers write into a channel window of
@@ -12,7 +16,7 @@ struct TView {
     void *ptr = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     int stride = 0;          // elements per pixel of the underlying buffer
-    int f32 = 0;             // element type: 0 bf16, 1 fp32
+    int dt = DT_BF16;        // element type (DT_*)
 };
 
 enum { ACT_LINEAR = 0, ACT_LEAKY = 1 };
@@ -21,12 +25,19 @@ struct ConvArgs {
     const void *in; int in_stride;       // elements per input pixel; Cin_pad channels are readable
     const void *wt;                      // packed filters [Cout_pad][Kpad], K index = (kh*k+kw)*Cin_pad + c
     const float *bias;                   // [Cout_pad] fp32 (BN folded)
-    void *out; int out_stride; int out_f32;
-    const void *res; int res_stride;     // residual (same type as in) or nullptr
+    void *out; int out_stride; int out_dt;
+    const void *res; int res_stride;     // residual (same type as out) or nullptr
+    // fp8 (e4m3) operands, DESIGN.md "fp8 scheme": value = code * scale.  in_dt selects the MFMA; `oscale` is the
+    // per-output-channel dequantisation factor of the accumulator (filter scale; input scales are folded into the
+    // filters), `out_inv_scale` = 1 / scale of the output tensor, `res_scale` = scale of the residual tensor.
+    int in_dt;
+    const float *oscale;                 // [Cout_pad] or nullptr (== 1)
+    float out_inv_scale, res_scale;
+    float mid_scale, mid_inv_scale;      // fused shortcut: this conv's own output scale (quantised before the add)
     int N, H, W, Cin_pad;
     int Ho, Wo, Cout;
     int ksize, stride, pad;
-    int Kpad;                            // multiple of 64
+    int Kpad;                            // multiple of 64 (bf16) / 128 (fp8) elements
     int act;
     const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
     // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
@@ -55,22 +66,26 @@ const char *conv_cfg_name(int cfg);
 // rough preference used when no autotune ran
 int conv_pick_cfg(const ConvArgs &a);
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
+// fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
+bool conv_cfg_fp8_ok(int cfg);
+hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 
 // ---- memory-bound operators (ew_ops.hip) ------------------------------------------------------
 hipError_t launch_preprocess(const void *img, int fmt /*0 u8, 1 f32*/, int n, int hw, float scale,
-                             void *out, int out_f32, int out_stride, hipStream_t s);
-hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_f32,
+                             void *out, int out_dt, int out_stride, hipStream_t s);
+hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_dt,
                             int out_stride, int out_c, hipStream_t s, float post_scale = 1.0f);
 hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s);
 hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s);
 hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s);
-hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s);
+// out = (a * sa + b * sb) * so   (the scales are the fp8 tensor scales; 1 for bf16 / fp32)
+hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s, float sa = 1.f, float sb = 1.f, float so = 1.f);
 hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s);
-hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s);   // dense NHWC fp32 copy
-hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s);
+hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s, float scale = 1.f);   // dense NHWC fp32 copy (* scale)
+hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, float scale = 1.f);   // (in * scale) -> view
 
 // ---- head decode + postprocess (post_ops.hip) ---------------------------------------------------
 struct DecodeArgs {

@@ -35,7 +35,8 @@ struct Layer {
     // conv
     int filters = 0, size = 0, stride = 1, pad = 0, bn = 0, act = ACT_LINEAR;
     int cin = 0, cin_pad = 0, kpad = 0, cout_pad = 0;
-    void *d_w = nullptr; float *d_b = nullptr;
+    void *d_w = nullptr; float *d_b = nullptr; float *d_sc = nullptr;   // filters, bias, fp8 per-channel dequant scale
+    int in_dt = DT_BF16;                 // operand type of this conv's MFMA (filters are stored in it)
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
@@ -53,7 +54,7 @@ struct Layer {
     TView out;
 };
 
-struct Storage { int def = 1 << 30, last = -1; size_t bytes = 0; int phys = -1; int stride = 0; bool f32 = false; bool persistent = false; };
+struct Storage { int def = 1 << 30, last = -1; size_t bytes = 0; int phys = -1; int stride = 0; int dt = DT_BF16; bool persistent = false; };
 
 }  // namespace
 
@@ -82,8 +83,13 @@ struct yolo_ctx {
     size_t weights_count = 0;
     double conv_flops = 0;
     int last_n = 0;
-    bool elem_f32() const { return dtype == YOLO_FP32; }
-    size_t esize() const { return dtype == YOLO_FP32 ? 4 : 2; }
+    // fp8 scheme: stored value = e4m3(real / scale).  user_scale[i] is what yolo_set_act_scales gave for
+    // layer i (1 by default); eff_scale[i] is the scale of the tensor layer i's view holds (inherited through
+    // upsample / maxpool / reorg / single-input route; NaN for multi-input routes, which are per channel).
+    std::vector<float> user_scale, eff_scale;
+    int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : DT_BF16; }
+    int gran() const { return dtype == YOLO_FP8 ? 16 : 8; }            // channel granule = one 16-B piece (8 for fp32 too)
+    size_t esize() const { return dt_size(act_dt()); }
 };
 
 namespace {
@@ -107,6 +113,25 @@ uint16_t f2bf(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// float -> OCP e4m3 (e4m3fn) code: round to nearest even, saturate at +-448, NaN -> 0x7f
+uint8_t f2e4m3(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 31) << 7);
+    if (f != f) return (uint8_t)(sign | 0x7f);
+    float a = fabsf(f);
+    if (a >= 448.f) return (uint8_t)(sign | 0x7e);
+    int e; frexpf(a, &e); e -= 1;                          // a in [2^e, 2^(e+1))
+    if (a == 0.f || e < -6) e = -6;                        // subnormal range shares the quantum of the first binade
+    const float quantum = ldexpf(1.f, e - 3);
+    const float q = nearbyintf(a / quantum);               // RNE under the default rounding mode; exact division
+    const float v = q * quantum;
+    if (v < ldexpf(1.f, -6)) return (uint8_t)(sign | (uint8_t)q);          // q in 0..7 (q == 8 is the first normal)
+    int e2; frexpf(v, &e2); e2 -= 1;
+    const int m = (int)((v / ldexpf(1.f, e2) - 1.f) * 8.f);
+    return (uint8_t)(sign | ((e2 + 7) << 3) | m);
 }
 
 // ---- cfg parsing (DN/parser.c:730-875 read_cfg + option_find_*) ------------------------------
@@ -167,8 +192,10 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
             else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
             if (L.size != 1 && L.size != 3) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: conv size %d unsupported on the device path", i, L.size);
-            L.cin = C; L.cin_pad = roundup(C, 8);
-            L.kpad = roundup(L.size * L.size * L.cin_pad, 64); L.cout_pad = roundup(L.filters, 256);
+            // fp8 mode: the first conv still reads the bf16 image (3 real channels padded to 8) with bf16 filters
+            L.in_dt = c->dtype == YOLO_FP8 ? (i == 0 ? DT_BF16 : DT_FP8) : c->act_dt();
+            L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
+            L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
             H = (H + 2 * L.pad - L.size) / L.stride + 1; W = (W + 2 * L.pad - L.size) / L.stride + 1; C = L.filters;
             c->conv_flops += 2.0 * L.size * L.size * L.cin * L.filters * (double)H * W;
             c->weights_count += (size_t)L.filters * (L.bn ? 4 : 1) + (size_t)L.filters * L.cin * L.size * L.size;
@@ -247,7 +274,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
             bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
-                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && (cj % 8 == 0) && (off % 8 == 0);
+                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && (cj % c->gran() == 0) && (off % c->gran() == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
             if (ok) { place_route[j] = i; place_off[j] = off; }
@@ -255,15 +282,15 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             off += cj;
         }
     }
-    auto new_storage = [&](int stride, bool f32, size_t pixels, bool persistent) {
-        Storage s; s.stride = stride; s.f32 = f32; s.bytes = pixels * (size_t)stride * (f32 ? 4 : c->esize()); s.persistent = persistent;
+    auto new_storage = [&](int stride, int dt, size_t pixels, bool persistent) {
+        Storage s; s.stride = stride; s.dt = dt; s.bytes = pixels * (size_t)stride * dt_size(dt); s.persistent = persistent;
         c->storages.push_back(s); return (int)c->storages.size() - 1;
     };
     // routes first (so producers can point into them)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.type == L_ROUTE && L.in.size() >= 2) {
-            L.storage = new_storage(roundup(L.C, 8), c->elem_f32(), (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+            L.storage = new_storage(roundup(L.C, c->gran()), c->act_dt(), (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
         }
     }
     for (int i = 0; i < NL; ++i) {
@@ -272,8 +299,8 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.type == L_ROUTE && L.in.size() == 1) { L.noop = true; int j = L.in[0]; if (j < 0) return fail(c, YOLO_ERR_UNSUPPORTED, "route to network input"); L.storage = c->layers[j].storage; L.ch_off = c->layers[j].ch_off; continue; }
         if (L.type == L_ROUTE) continue;
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
-        else if (L.head) L.storage = new_storage(roundup(L.C, 4), true, (size_t)c->max_batch * L.H * L.W, true);
-        else L.storage = new_storage(roundup(L.C, 8), c->elem_f32(), (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+        else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
+        else L.storage = new_storage(roundup(L.C, c->gran()), c->act_dt(), (size_t)c->max_batch * L.H * L.W, c->keep_layers);
     }
     // a conv whose shortcut was fused writes the shortcut layer's tensor
     for (int i = 0; i + 1 < NL; ++i) {
@@ -326,13 +353,14 @@ int allocate(yolo_ctx *c)
         if (L.storage < 0) continue;
         Storage &s = c->storages[L.storage];
         if (s.phys < 0) return fail(c, YOLO_ERR_STATE, "internal: storage without buffer");
-        L.out.n = c->max_batch; L.out.h = L.H; L.out.w = L.W; L.out.c = L.C; L.out.stride = s.stride; L.out.f32 = s.f32;
-        L.out.ptr = (char *)c->phys[s.phys] + (size_t)L.ch_off * (s.f32 ? 4 : c->esize());
+        L.out.n = c->max_batch; L.out.h = L.H; L.out.w = L.W; L.out.c = L.C; L.out.stride = s.stride; L.out.dt = s.dt;
+        L.out.ptr = (char *)c->phys[s.phys] + (size_t)L.ch_off * dt_size(s.dt);
     }
     // network input: 3 real channels padded to 8
-    size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 8 * c->esize();
+    c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : DT_BF16;            // fp8 mode keeps the image in bf16
+    size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 8 * dt_size(c->input.dt);
     HIPCK(c, hipMalloc(&c->input.ptr, in_bytes));
-    c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8; c->input.f32 = c->elem_f32();
+    c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8;
     HIPCK(c, hipMalloc(&c->d_zeros, 4096)); HIPCK(c, hipMemsetAsync(c->d_zeros, 0, 4096, c->stream));
     c->stage_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 3 * 4;
     HIPCK(c, hipMalloc(&c->d_stage, c->stage_bytes));
@@ -345,9 +373,10 @@ int allocate(yolo_ctx *c)
     HIPCK(c, hipMalloc((void **)&c->d_counts, (size_t)c->max_batch * 4));
     // filters
     for (auto &L : c->layers) if (L.type == L_CONV) {
-        size_t wb = (size_t)L.cout_pad * L.kpad * c->esize();
+        size_t wb = (size_t)L.cout_pad * L.kpad * dt_size(L.in_dt);
         HIPCK(c, hipMalloc(&L.d_w, wb)); HIPCK(c, hipMemsetAsync(L.d_w, 0, wb, c->stream));
         HIPCK(c, hipMalloc((void **)&L.d_b, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_b, 0, (size_t)L.cout_pad * 4, c->stream));
+        if (L.in_dt == DT_FP8) { HIPCK(c, hipMalloc((void **)&L.d_sc, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_sc, 0, (size_t)L.cout_pad * 4, c->stream)); }
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
     return YOLO_OK;
@@ -358,8 +387,16 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     ConvArgs a; memset(&a, 0, sizeof a);
     TView in = view_of(c, L.in[0]);
     a.in = in.ptr; a.in_stride = in.stride; a.wt = L.d_w; a.bias = L.d_b;
-    a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_f32 = L.out.f32;
+    a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_dt = L.out.dt; a.in_dt = L.in_dt; a.oscale = L.d_sc;
+    a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
+    const int li = (int)(&L - c->layers.data());
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
+    if (L.out.dt == DT_FP8) {
+        if (L.residual_from >= -1) {     // fused shortcut: this conv writes layer li+1's tensor
+            a.mid_scale = c->user_scale[li]; a.mid_inv_scale = 1.f / c->user_scale[li];
+            a.res_scale = c->eff_scale[L.residual_from]; a.out_inv_scale = 1.f / c->eff_scale[li + 1];
+        } else a.out_inv_scale = 1.f / c->eff_scale[li];
+    }
     a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
     a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = L.act; a.zeros = c->d_zeros;
     conv_finalize(a);
@@ -375,14 +412,21 @@ int run_layer(yolo_ctx *c, int i, int n)
     case L_CONV: {
         ConvArgs a = conv_args(c, L, n);
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
-        else {
+        else if (L.in_dt == DT_FP8) {
+            int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
+            HIPCK(c, launch_conv_fp8(a, cfg, s));
+        } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
         break; }
     case L_SHORTCUT:
-        if (!L.noop) HIPCK(c, launch_add(nview(view_of(c, L.in[0])), nview(view_of(c, L.in[1])), nview(L.out), s));
+        if (!L.noop) {
+            float sa = 1.f, sb = 1.f, so = 1.f;
+            if (c->dtype == YOLO_FP8) { sa = c->eff_scale[L.in[0]]; sb = c->eff_scale[L.in[1]]; so = 1.f / c->eff_scale[i]; }
+            HIPCK(c, launch_add(nview(view_of(c, L.in[0])), nview(view_of(c, L.in[1])), nview(L.out), s, sa, sb, so));
+        }
         break;
     case L_ROUTE:
         for (size_t k = 0; k < L.copy_inputs.size(); ++k) {
@@ -420,7 +464,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
         HIPCK(c, hipMemcpyAsync(c->d_stage, images, npix * 3 * (fmt == YOLO_IMG_U8 ? 1 : 4), hipMemcpyHostToDevice, c->stream));
         src = c->d_stage;
     }
-    HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.f32, 8, c->stream));
+    HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream));
     return YOLO_OK;
 }
 
@@ -472,13 +516,16 @@ struct OpScope {
 };
 thread_local std::string g_op_err;
 
-TView make_view(void *p, int n, int h, int w, int c, int stride, int f32) { TView v; v.ptr = p; v.n = n; v.h = h; v.w = w; v.c = c; v.stride = stride; v.f32 = f32; return v; }
+TView make_view(void *p, int n, int h, int w, int c, int stride, int dt) { TView v; v.ptr = p; v.n = n; v.h = h; v.w = w; v.c = c; v.stride = stride; v.dt = dt; return v; }
 
-// fold + pack one conv's parameters (host).  w_oihw: [cout][cin][k][k]
-void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, bool f32, std::vector<uint8_t> &wbuf, std::vector<float> &bias)
+// fold + pack one conv's parameters (host).  w_oihw: [cout][cin][k][k].  wdt: element type of the packed filters.
+// fp8: `in_scale` (per input channel, or null = 1) is folded into the filters first, then every output channel c is
+// scaled so that its largest |w| maps to 448: code = e4m3(w * in_scale / osc[c]), osc[c] = max|w * in_scale| / 448.
+void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc)
 {
     const int n = L.filters, k = L.size, cin = L.cin;
-    bias.assign(L.cout_pad, 0.f);
+    bias.assign(L.cout_pad, 0.f); osc.assign(L.cout_pad, 1.f);
     std::vector<float> scale(n, 1.f);
     if (L.bn) {
         const float *beta = bn_or_bias, *gamma = beta + n, *mean = gamma + n, *var = mean + n;
@@ -489,17 +536,58 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, boo
     } else {
         for (int o = 0; o < n; ++o) bias[o] = bn_or_bias[o];
     }
-    const size_t es = f32 ? 4 : 2;
+    const size_t es = dt_size(wdt);
     wbuf.assign((size_t)L.cout_pad * L.kpad * es, 0);
-    for (int o = 0; o < n; ++o)
+    std::vector<float> row((size_t)cin * k * k);
+    for (int o = 0; o < n; ++o) {
+        float amax = 0.f;
         for (int ci = 0; ci < cin; ++ci)
-            for (int kh = 0; kh < k; ++kh)
-                for (int kw = 0; kw < k; ++kw) {
-                    float v = w_oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] * scale[o];
-                    size_t idx = (size_t)o * L.kpad + (size_t)(kh * k + kw) * L.cin_pad + ci;
-                    if (f32) memcpy(&wbuf[idx * 4], &v, 4);
-                    else { uint16_t b = f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
-                }
+            for (int t = 0; t < k * k; ++t) {
+                float v = w_oihw[((size_t)o * cin + ci) * k * k + t] * scale[o];
+                if (wdt == DT_FP8 && in_scale) v *= in_scale[ci];
+                row[(size_t)ci * k * k + t] = v; amax = std::max(amax, fabsf(v));
+            }
+        if (wdt == DT_FP8) osc[o] = amax > 0.f ? amax / FP8_MAX : 1.f;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < k * k; ++t) {
+                const float v = row[(size_t)ci * k * k + t];
+                const size_t idx = (size_t)o * L.kpad + (size_t)t * L.cin_pad + ci;        // t = kh * k + kw
+                if (wdt == DT_F32) memcpy(&wbuf[idx * 4], &v, 4);
+                else if (wdt == DT_FP8) wbuf[idx] = f2e4m3(v / osc[o]);
+                else { uint16_t b = f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
+            }
+    }
+}
+
+// fp8: scale of the tensor each layer's view holds, and per-input-channel scales of a conv
+void resolve_scales(yolo_ctx *c)
+{
+    const int NL = (int)c->layers.size();
+    if ((int)c->user_scale.size() != NL) c->user_scale.assign(NL, 1.f);
+    c->eff_scale.assign(NL, 1.f);
+    for (int i = 0; i < NL; ++i) {
+        const Layer &L = c->layers[i];
+        switch (L.type) {
+        case L_CONV: c->eff_scale[i] = (L.residual_from >= -1 && i + 1 < NL) ? c->user_scale[i + 1] : c->user_scale[i]; break;
+        case L_SHORTCUT: c->eff_scale[i] = c->user_scale[i]; break;
+        case L_ROUTE: c->eff_scale[i] = L.in.size() == 1 ? c->eff_scale[L.in[0]] : NAN; break;
+        case L_UPSAMPLE: case L_MAXPOOL: case L_REORG: c->eff_scale[i] = c->eff_scale[L.in[0]]; break;
+        default: break;
+        }
+    }
+}
+// scale of every logical channel of layer idx's output (multi-input routes concatenate their sources)
+void channel_scales(const yolo_ctx *c, int idx, std::vector<float> &out)
+{
+    const Layer &L = c->layers[idx];
+    if (L.type == L_ROUTE && L.in.size() > 1) { for (int j : L.in) channel_scales(c, j, out); return; }
+    if (L.type == L_REORG) {             // channel order is scrambled but every source channel has the same scale
+        std::vector<float> src; channel_scales(c, L.in[0], src);
+        for (int k = 0; k < L.C; ++k) out.push_back(src[0]);
+        return;
+    }
+    if (L.type == L_ROUTE || L.type == L_UPSAMPLE || L.type == L_MAXPOOL) { channel_scales(c, L.in[0], out); return; }
+    for (int k = 0; k < L.C; ++k) out.push_back(c->eff_scale[idx]);
 }
 
 }  // namespace
@@ -512,7 +600,7 @@ yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
     auto bail = [&](yolo_ctx *c, const std::string &m) -> yolo_ctx * { if (err && err_len) snprintf(err, err_len, "%s", m.c_str()); if (c) yolo_destroy(c); return nullptr; };
     if (!cfg || cfg->struct_size != sizeof(yolo_config)) return bail(nullptr, "yolo_create: bad yolo_config (struct_size)");
     if (cfg->max_batch < 1) return bail(nullptr, "yolo_create: max_batch < 1");
-    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32) return bail(nullptr, "yolo_create: dtype");
+    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32 && cfg->dtype != YOLO_FP8) return bail(nullptr, "yolo_create: dtype");
     yolo_ctx *c = new yolo_ctx();
     c->device = cfg->device; c->max_batch = cfg->max_batch; c->dtype = cfg->dtype; c->semantics = cfg->semantics;
     c->decode = cfg->decode; c->keep_layers = cfg->keep_layers;
@@ -525,6 +613,7 @@ yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
     if (!parse_cfg(cfg->cfg_text, secs, perr)) return bail(c, perr);
     if (build_plan(c, secs) != YOLO_OK) return bail(c, c->err);
     if (allocate(c) != YOLO_OK) return bail(c, c->err);
+    resolve_scales(c);
     return c;
 }
 
@@ -534,7 +623,7 @@ void yolo_destroy(yolo_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void *p : c->phys) if (p) hipFree(p);
-    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); }
+    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -546,6 +635,19 @@ const char *yolo_last_error(const yolo_ctx *c) { return c ? c->err.c_str() : g_o
 
 size_t yolo_weights_count(const yolo_ctx *c) { return c ? c->weights_count : 0; }
 
+int yolo_set_act_scales(yolo_ctx *c, const float *scales, int n)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (c->dtype != YOLO_FP8) return fail(c, YOLO_ERR_STATE, "activation scales only exist in the fp8 configuration");
+    if (!scales || n != (int)c->layers.size()) return fail(c, YOLO_ERR_INVALID, "need one scale per layer (%zu)", c->layers.size());
+    for (int i = 0; i < n; ++i) if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) return fail(c, YOLO_ERR_INVALID, "layer %d: scale must be finite and > 0", i);
+    c->user_scale.assign(scales, scales + n);
+    resolve_scales(c);
+    c->weights_loaded = false;           // filters absorb the input scales: they have to be packed again
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0;
+    return YOLO_OK;
+}
+
 int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
 {
     if (!c) return YOLO_ERR_INVALID;
@@ -553,14 +655,21 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
     if (n != c->weights_count) return fail(c, YOLO_ERR_IO, "weights stream has %zu floats, topology needs %zu", n, c->weights_count);
     HIPCK(c, hipSetDevice(c->device));
     const float *p = flat;
-    std::vector<uint8_t> wbuf; std::vector<float> bias;
+    std::vector<uint8_t> wbuf; std::vector<float> bias, osc;
+    resolve_scales(c);
     for (auto &L : c->layers) {
         if (L.type != L_CONV) continue;
         const float *params = p; p += (size_t)L.filters * (L.bn ? 4 : 1);
         const float *w = p; p += (size_t)L.filters * L.cin * L.size * L.size;
-        pack_conv(L, params, w, c->elem_f32(), wbuf, bias);
+        std::vector<float> in_sc;
+        if (L.in_dt == DT_FP8) {
+            channel_scales(c, L.in[0], in_sc);
+            if ((int)in_sc.size() != L.cin) return fail(c, YOLO_ERR_STATE, "internal: scale vector of %zu for %d channels", in_sc.size(), L.cin);
+        }
+        pack_conv(L, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc);
         HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+        if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));
     }
     c->weights_loaded = true;
     return YOLO_OK;
@@ -595,7 +704,8 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
     double b = 0;
     for (auto &L : c->layers) if (L.type == L_CONV) {
         TView in = view_of(c, L.in[0]);
-        b += (double)n * in.h * in.w * L.cin * 2.0 + (double)n * L.H * L.W * L.filters * 2.0 + (double)L.filters * L.cin * L.size * L.size * 2.0;
+        const double ie = (double)dt_size(L.in_dt), oe = (double)dt_size(L.out.dt);
+        b += (double)n * in.h * in.w * L.cin * ie + (double)n * L.H * L.W * L.filters * oe + (double)L.filters * L.cin * L.size * L.size * ie;
     }
     return b;
 }
@@ -623,7 +733,7 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
         HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3));
         HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
     }
-    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.f32, 8, 8, c->stream);
+    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -698,7 +808,12 @@ int yolo_layer_output(yolo_ctx *c, int index, int n, float *out, size_t out_floa
     HIPCK(c, hipSetDevice(c->device));
     float *tmp = nullptr; HIPCK(c, hipMalloc((void **)&tmp, need * 4));
     TView v = L.out; v.n = n;
-    hipError_t e = launch_to_f32(v, tmp, c->stream);
+    float vs = 1.f;
+    if (v.dt == DT_FP8) {
+        vs = c->eff_scale[index];
+        if (vs != vs) { hipFree(tmp); return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d concatenates tensors with different fp8 scales; read its sources", index); }
+    }
+    hipError_t e = launch_to_f32(v, tmp, c->stream, vs);
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, need * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(tmp);
@@ -768,24 +883,26 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
 {
     if (!c) return YOLO_ERR_INVALID;
     if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "weights not loaded");
-    if (c->dtype != YOLO_BF16) return YOLO_OK;
+    if (c->dtype == YOLO_FP32) return YOLO_OK;
     if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
     HIPCK(c, hipSetDevice(c->device));
     hipEvent_t e0, e1; HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    auto launch = [&](const ConvArgs &a, int cfg) { return a.in_dt == DT_FP8 ? launch_conv_fp8(a, cfg, c->stream) : launch_conv_bf16(a, cfg, c->stream); };
     std::map<std::string, int> memo;
     for (auto &L : c->layers) {
         if (L.type != L_CONV) continue;
         ConvArgs a = conv_args(c, L, n);
-        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.out_f32, a.res != nullptr);
+        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d%d_%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.in_dt, a.out_dt, a.res != nullptr);
         auto it = memo.find(key);
         if (it != memo.end()) { L.tile_cfg = it->second; continue; }
         float best = 1e30f; int best_cfg = conv_pick_cfg(a);
         for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
             const int cfg = ci == conv_num_cfgs() ? CONV_CFG_DIRECT : ci;
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) continue;
-            if (launch_conv_bf16(a, cfg, c->stream) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm-up
+            if (a.in_dt == DT_FP8 && !conv_cfg_fp8_ok(cfg)) continue;
+            if (launch(a, cfg) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm-up
             HIPCK(c, hipEventRecord(e0, c->stream));
-            for (int r = 0; r < iters; ++r) launch_conv_bf16(a, cfg, c->stream);
+            for (int r = 0; r < iters; ++r) launch(a, cfg);
             HIPCK(c, hipEventRecord(e1, c->stream)); HIPCK(c, hipEventSynchronize(e1));
             float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1));
             if (getenv("YOLO_TUNE_VERBOSE")) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms\n", key, cfg, conv_cfg_name(cfg), ms / iters);
@@ -824,38 +941,42 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
 {
     if (!x || !w_hwio || !out || n < 1 || (k != 1 && k != 3) || stride < 1) { g_op_err = "conv2d: bad arguments"; return YOLO_ERR_INVALID; }
     OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
-    const bool f32 = dtype == YOLO_FP32; const size_t es = f32 ? 4 : 2;
-    Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act;
-    L.cin = cin; L.cin_pad = roundup(cin, 8); L.kpad = roundup(k * k * L.cin_pad, 64); L.cout_pad = roundup(cout, 256);
+    // dtype YOLO_FP8: x, residual and the result are e4m3 tensors of scale 1 (the inputs are quantised here first)
+    const bool f32 = dtype == YOLO_FP32; const int dt = f32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : DT_BF16; const size_t es = dt_size(dt);
+    const int gr = dt == DT_FP8 ? 16 : 8;
+    Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act; L.in_dt = dt;
+    L.cin = cin; L.cin_pad = roundup(cin, gr); L.kpad = roundup(k * k * L.cin_pad, dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(cout, 256);
     const int ho = (h + 2 * L.pad - k) / stride + 1, wo = (w + 2 * L.pad - k) / stride + 1;
     // HWIO -> OIHW for the common packer
     std::vector<float> oihw((size_t)cout * cin * k * k), b0(cout, 0.f);
     for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int ci = 0; ci < cin; ++ci) for (int o = 0; o < cout; ++o)
         oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] = w_hwio[(((size_t)kh * k + kw) * cin + ci) * cout + o];
     if (bias) memcpy(b0.data(), bias, (size_t)cout * 4);
-    std::vector<uint8_t> wbuf; std::vector<float> bv; pack_conv(L, b0.data(), oihw.data(), f32, wbuf, bv);
+    std::vector<uint8_t> wbuf; std::vector<float> bv, osc; pack_conv(L, b0.data(), oihw.data(), dt, nullptr, wbuf, bv, osc);
     void *d_w = S.upload(wbuf.data(), wbuf.size()); float *d_b = (float *)S.upload(bv.data(), bv.size() * 4);
+    float *d_sc = dt == DT_FP8 ? (float *)S.upload(osc.data(), osc.size() * 4) : nullptr;
     float *d_x32 = (float *)S.upload(x, (size_t)n * h * w * cin * 4);
     void *d_x = S.alloc((size_t)n * h * w * L.cin_pad * es);
-    const int cstride = roundup(cout, 8);
+    const int cstride = roundup(cout, gr);
     void *d_o = S.alloc((size_t)n * ho * wo * cstride * es); float *d_o32 = (float *)S.alloc((size_t)n * ho * wo * cout * 4);
     void *d_r = nullptr;
     void *d_z = S.alloc(4096);
     if (S.rc) { g_op_err = "conv2d: allocation failed"; return S.rc; }
-    TView vx = make_view(d_x, n, h, w, cin, L.cin_pad, f32);
+    TView vx = make_view(d_x, n, h, w, cin, L.cin_pad, dt);
     if (!S.ok(launch_from_f32(d_x32, vx, S.s))) { g_op_err = S.err; return S.rc; }
     if (residual) {
         float *d_r32 = (float *)S.upload(residual, (size_t)n * ho * wo * cout * 4); d_r = S.alloc((size_t)n * ho * wo * cstride * es);
         if (S.rc) return S.rc;
-        if (!S.ok(launch_from_f32(d_r32, make_view(d_r, n, ho, wo, cout, cstride, f32), S.s))) { g_op_err = S.err; return S.rc; }
+        if (!S.ok(launch_from_f32(d_r32, make_view(d_r, n, ho, wo, cout, cstride, dt), S.s))) { g_op_err = S.err; return S.rc; }
     }
     ConvArgs a; memset(&a, 0, sizeof a);
-    a.in = d_x; a.in_stride = L.cin_pad; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = cstride; a.out_f32 = f32;
+    a.in = d_x; a.in_stride = L.cin_pad; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = cstride; a.out_dt = dt; a.in_dt = dt;
+    a.oscale = d_sc; a.out_inv_scale = a.res_scale = a.mid_scale = a.mid_inv_scale = 1.f;
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = act; a.zeros = d_z;
     conv_finalize(a);
     hipError_t e;
-    if (!f32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % 64 == 0) {
+    if (dt == DT_BF16 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % 64 == 0) {
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build, printed to stderr
         const long tiles = (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
         a.dbg = (unsigned long long *)S.alloc((size_t)tiles * 4 * 6 * 8);
@@ -868,9 +989,11 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz\n",
                 cnt, kt, w / cnt / kt, is / cnt / kt, mm / cnt / kt, lp / cnt / kt, ep / cnt, mhz / cnt);
     } else
-        e = f32 ? launch_conv_f32(a, S.s) : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
+        e = f32 ? launch_conv_f32(a, S.s)
+                : dt == DT_FP8 ? launch_conv_fp8(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s)
+                               : launch_conv_bf16(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s);
     if (!S.ok(e)) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
-    if (!S.ok(launch_to_f32(make_view(d_o, n, ho, wo, cout, cstride, f32), d_o32, S.s))) { g_op_err = S.err; return S.rc; }
+    if (!S.ok(launch_to_f32(make_view(d_o, n, ho, wo, cout, cstride, dt), d_o32, S.s))) { g_op_err = S.err; return S.rc; }
     S.download(out, d_o32, (size_t)n * ho * wo * cout * 4);
     if (S.rc) g_op_err = "conv2d: " + std::string(hipGetErrorString(hipGetLastError()));
     return S.rc;

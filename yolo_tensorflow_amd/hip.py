@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-BF16, FP32 = 0, 1
+BF16, FP32, FP8 = 0, 1, 2
 SEM_TF, SEM_DARKNET = 0, 1
 DECODE_RATIO, DECODE_PIXEL = 0, 1
 HOST, DEVICE = 0, 1
@@ -24,7 +24,7 @@ BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4")
 
 EXPORTS = [
     "yolo_create", "yolo_destroy", "yolo_last_error", "yolo_load_darknet_weights", "yolo_set_weights",
-    "yolo_weights_count", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
+    "yolo_weights_count", "yolo_set_act_scales", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
@@ -62,6 +62,7 @@ def load_library():
     l.yolo_load_darknet_weights.argtypes = [P, C.c_char_p, I]
     l.yolo_set_weights.argtypes = [P, FP, C.c_size_t]
     l.yolo_weights_count.argtypes = [P]; l.yolo_weights_count.restype = C.c_size_t
+    l.yolo_set_act_scales.argtypes = [P, P, I]
     l.yolo_input_size.argtypes = [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]
     for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_synchronize"):
         getattr(l, n).argtypes = [P]
@@ -154,6 +155,11 @@ class Engine:
     # ---- weights ----
     def weights_count(self):
         return self.lib.yolo_weights_count(self.ctx)
+
+    def set_act_scales(self, scales):
+        """FP8 engines: one activation scale per cfg layer (code = e4m3(value / scale)); call before loading weights."""
+        sc = np.ascontiguousarray(scales, dtype=np.float32)
+        self._check(self.lib.yolo_set_act_scales(self.ctx, sc.ctypes.data, sc.size), "yolo_set_act_scales")
 
     def load_weights(self, path, header_ints=0):
         self._check(self.lib.yolo_load_darknet_weights(self.ctx, os.fsencode(path), header_ints), "yolo_load_darknet_weights")
