@@ -9,4 +9,4 @@ for (n, h, cin, cout, k) in ((32, 26, 256, 512, 3), (32, 52, 128, 256, 3), (32, 
     x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
     w = (rng.standard_normal((k, k, cin, cout)) * 0.05).astype(np.float32)
     print("shape", (n, h, cin, cout, k), file=sys.stderr)
-    hip.op_conv2d(x, w, None, act=1)
+    hip.op_conv2d(x, w, None, act=1, dtype={"bf16": hip.BF16, "fp8": hip.FP8}[os.environ.get("DTYPE", "bf16")])

@@ -3,12 +3,12 @@ import sys, os, json
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
-B = int(os.environ.get("B", "32")); size = int(os.environ.get("SIZE", "416"))
+B = int(os.environ.get("B", "32")); size = int(os.environ.get("SIZE", "416")); DT = os.environ.get("DTYPE", "bf16")
 txt = IO.with_input_size(IO.cfg_text("yolov3"), size); secs = IO.parse_cfg(txt)
-eng = hip.Engine(txt, max_batch=B); eng.set_weights(IO.synth_weights(secs, 0))
+eng = hip.Engine(txt, max_batch=B, dtype={"bf16": hip.BF16, "fp8": hip.FP8}[DT]); eng.set_weights(IO.synth_weights(secs, 0))
 img = np.random.default_rng(0).integers(0, 256, (B, size, size, 3), dtype=np.uint8)
 eng.forward(img, want_detections=False)
-plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_bf16.json" % (size, B))
+plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (size, B, DT))
 if os.path.exists(plan) and os.environ.get("TUNE", "0") != "1":
     eng.set_tile_configs(json.load(open(plan))["cfgs"])
 else:
@@ -30,4 +30,4 @@ for i, ((kind, h, w, c, cin), t) in enumerate(zip(shapes, ms)):
         if t > 0: print("%4d %-14s %4d %4d %5d                  %7.4f" % (i, kind, h, w, c, t))
     bykind[key] = bykind.get(key, 0.0) + t
 print("by kind:", {k: round(v, 3) for k, v in bykind.items()})
-print("sum of layers %.3f ms;  forward %.3f ms" % (tot, eng.time_forward(B, 20)))
+print("sum of layers %.3f ms;  forward %.3f ms (conv %.3f ms)" % ((tot,) + tuple(eng.time_forward(B, 20))))

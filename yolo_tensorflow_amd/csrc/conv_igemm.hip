@@ -82,13 +82,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     constexpr int GP = (BP + RG - 1) / RG, GC = (BC + RG - 1) / RG;
     // every wave issues the same number of LDS-DMA instructions per K-step (the counted vmcnt relies on it): group
     // counts are padded up to a multiple of the wave count; padded rows get an out-of-range offset (zeros, no traffic)
-    // Experiment kept for the record (disabled): with WP == 1 no filter row is shared between waves, so the filter
-    // fragments could go global -> VGPR directly (one K-step ahead, ping-pong registers) and skip LDS.  Measured on
-    // MI355X it is SLOWER (K-step 2114 -> 2900 cycles for p176c128): a fragment-shaped load touches 16 rows x 64 B per
-    // instruction, which the texture addresser handles far worse than the 8 x 128-B rows of an LDS-DMA piece.
-    constexpr bool WDIRECT = false;
-    static_assert(!WDIRECT || NS == 2, "direct filter fragments are pipelined exactly one K-step ahead");
-    constexpr int LA = (GP + NW - 1) / NW, LB = WDIRECT ? 0 : (GC + NW - 1) / NW;
+    // (Tried and dropped: with WP == 1 no filter row is shared between waves, so the filter fragments could go
+    // global -> VGPR directly and skip LDS.  Measured SLOWER, K-step 2114 -> 2900 cycles for p176c128: a
+    // fragment-shaped load touches 16 rows x 64 B per instruction, which the texture addresser handles far worse than
+    // the 8 x 128-B rows of an LDS-DMA piece.)
+    constexpr int LA = (GP + NW - 1) / NW, LB = (GC + NW - 1) / NW;
     constexpr int L = LA + LB;
     constexpr int BPL = LA * NW * RG, BCL = LB * NW * RG;    // rows of the LDS images
     constexpr int STAGE_BYTES = (BPL + BCL) * RB;
@@ -179,19 +177,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (!UNI)
         while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
     int s_wk = 0;                                       // byte offset of the K-step in a filter row
-    // direct filter fragments: lane (l15, lq) of tile i needs W[ct*BC + (wci*TC+i)*16 + l15][k0 + (kk*4+lq)*8 .. +7]
-    unsigned wfoff[TC];
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-        wfoff[i] = (unsigned)((ct * BC + (wci * TC + i) * 16 + (lane & 15)) * a.Kpad + (lane >> 4) * 8) * 2u;
-    auto load_wfrag = [&](bf16x8 (&dst)[TC][2], int koff_bytes) {
-#pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            dst[i][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wfoff[i], koff_bytes, 0));
-            dst[i][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wfoff[i] + 64u, koff_bytes, 0));
-        }
-    };
-
     auto stage = [&](char *sbase) {
         char *dx = sbase + wid * 1024;
         char *dw = sbase + BPL * RB + wid * 1024;
@@ -236,8 +221,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 #pragma unroll
     for (int t = 0; t < D; ++t)
         if (t < KT && is_loader) stage(smem + t * STAGE_BYTES);
-    bf16x8 fwc[TC][2], fwn[TC][2];             // WDIRECT: filter fragments of the current / next K-step
-    if (WDIRECT) load_wfrag(fwc, 0);
 
     const int l15 = lane & 15, lq = lane >> 4;
     // fragment read offsets inside a stage (two K-halves), constant over the loop
@@ -255,71 +238,113 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     };
     unsigned long long rt0 = 0;
     if (DIAG) { t_all0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    // one K-step; `fcur` / `fnext` are the filter-fragment register sets of this and the next step (WDIRECT only: the
-    // loop is unrolled by two so the sets ping-pong without a copy, which would force an early wait on the loads)
-    auto kstep = [&](int kt, bf16x8 (&fcur)[TC][2], bf16x8 (&fnext)[TC][2]) {
+    // one K-step.  `fill` / `sb`: the stage being filled and the stage being multiplied.  They are distinct __restrict__ parameters
+    // on purpose: hipcc orders every ds_read behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0) before the first
+    // fragment read of each K-step, i.e. the loads just issued for the NEXT step were waited for before this step's
+    // MFMAs) unless alias-scope metadata proves the DMA target and the read are different memory; restrict parameters
+    // of an inlined function are what produces that metadata.
+    auto kstep = [&](int kt, char *__restrict__ fill, const char *__restrict__ sb) {
         const unsigned long long s0 = stamp();
         // K-step kt has landed once at most (D-1) younger K-steps' loads remain outstanding (in-order counter)
         if (is_loader) { if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>(); }
         block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
         const unsigned long long s1 = stamp();
-        if (kt + D < KT && is_loader) {
-            stage(smem + nxt * STAGE_BYTES);
-            if (WDIRECT) load_wfrag(fnext, (kt + 1) * RB);
-        }
+        if (kt + D < KT && is_loader) stage(fill);
         const unsigned long long s2 = stamp();
-        const char *sb = smem + cur * STAGE_BYTES;
+        // Fragment reads are software-pipelined PD MFMA groups ahead and PINNED there with sched_group_barrier: left
+        // alone the scheduler hoists every ds_read of the (half) step above the first MFMA and waits lgkmcnt(0), so
+        // the LDS pipe and the MFMA pipe take turns instead of overlapping (all four waves are in the same phase).
+        // A "group" is the TC MFMAs that share one pixel fragment.
         if (EB == 1) {
-            // e4m3: one K = 128 MFMA per tile pair.  Lane (l15, lq) supplies bytes [32*lq, 32*lq + 32) of its row
-            // for BOTH operands (chunks 2*lq and 2*lq+1 behind the same XOR swizzle), so the pairing of K indices
-            // inside the instruction is consistent whatever its internal order (tools/probe/mfma_fp8.hip).
+            // e4m3: one K = 128 MFMA per tile pair.  Lane (l15, lq) supplies 16-B chunks lq and lq + 4 of its row for
+            // BOTH operands, so the pairing of K indices inside the instruction is consistent whatever its internal
+            // order (tools/probe/mfma_fp8.hip).  Those are the chunks of the two bf16 half-steps, i.e. the one
+            // assignment for which the XOR swizzle is conflict-free under ds_read_b128's lane groups; the "natural"
+            // chunks 2*lq, 2*lq + 1 collide two-way in every group (measured: +35 % on the fragment-read phase).
             if (is_consumer) {
-                const int swa = ((2 * lq) ^ (l15 & 7)) << 4, swb = ((2 * lq + 1) ^ (l15 & 7)) << 4;
+                constexpr int PD = TP < 3 ? TP : 3;
                 i32x8 fw[TC], fx[TP];
                 auto frag = [&](const char *row) -> i32x8 {
-                    const uint4 lo = *(const uint4 *)(row + swa), hi = *(const uint4 *)(row + swb);
+                    const uint4 lo = *(const uint4 *)(row + sw0), hi = *(const uint4 *)(row + sw1);
                     return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
                 };
 #pragma unroll
                 for (int i = 0; i < TC; ++i) fw[i] = frag(sb + offw + i * 16 * RB);
 #pragma unroll
-                for (int j = 0; j < TP; ++j) fx[j] = frag(sb + offx + j * 16 * RB);
+                for (int j = 0; j < PD; ++j) fx[j] = frag(sb + offx + j * 16 * RB);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    if (j + PD < TP) fx[j + PD] = frag(sb + offx + (j + PD) * 16 * RB);
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fx[j], acc[i][j], 0, 0, 0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TC + PD), 0);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    if (j + PD < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                }
+            }
+        } else if (is_consumer) {
+            constexpr int KH = BK / 32;                 // K halves of 32 per step
+            constexpr int NG = KH * TP;                 // MFMA groups per step
+            constexpr int PD = NG < 4 ? NG : 4;
+            bf16x8 fw[KH][TC], fx[NG];
+            auto rdw = [&](int kk) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) fw[kk][i] = *(const bf16x8 *)(sb + offw + i * 16 * RB + (kk ? sw1 : sw0));
+            };
+            auto rdx = [&](int g) {
+                const int kk = g / TP, j = g - kk * TP;
+                fx[g] = *(const bf16x8 *)(sb + offx + j * 16 * RB + (kk ? sw1 : sw0));
+            };
+            // the second half's filter fragments are read when the pixel prefetch first reaches that half
+            constexpr bool W1_UPFRONT = KH == 2 && PD >= TP;
+            rdw(0);
+            if (W1_UPFRONT) rdw(1);
+#pragma unroll
+            for (int g = 0; g < PD; ++g) rdx(g);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + PD < NG) {
+                    if (KH == 2 && !W1_UPFRONT && g + PD == TP) rdw(1);
+                    rdx(g + PD);
+                }
+                const int kk = g / TP, j = g - kk * TP;
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fx[j], acc[i][j], 0, 0, 0, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][i], fx[g], acc[i][j], 0, 0, 0);
             }
-        } else if (is_consumer)
+            __builtin_amdgcn_sched_group_barrier(0x100, TC + (W1_UPFRONT ? TC : 0) + PD, 0);
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            const int sw = kk ? sw1 : sw0;
-            bf16x8 fw[TC], fx[TP];
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-                if (WDIRECT) fw[i] = fcur[i][kk];
-                else fw[i] = *(const bf16x8 *)(sb + offw + i * 16 * RB + sw);
+            for (int g = 0; g < NG; ++g) {
+                if (g + PD < NG) {
+                    if (KH == 2 && !W1_UPFRONT && g + PD == TP) __builtin_amdgcn_sched_group_barrier(0x100, TC, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TP; ++j) fx[j] = *(const bf16x8 *)(sb + offx + j * 16 * RB + sw);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
         if (DIAG) {
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
             const unsigned long long s3 = stamp();
             t_wait += s1 - s0; t_issue += s2 - s1; t_mma += s3 - s2;
         }
-        cur = cur + 1 == NS ? 0 : cur + 1;
-        nxt = nxt + 1 == NS ? 0 : nxt + 1;
     };
     {
         int kt = 0;
-        for (; kt + 1 < KT; kt += 2) { kstep(kt, fwc, fwn); kstep(kt + 1, fwn, fwc); }
-        if (kt < KT) kstep(kt, fwc, fwn);
+        if (NS == 2) {
+            char *const s0 = smem, *const s1 = smem + STAGE_BYTES;
+            for (; kt + 1 < KT; kt += 2) { kstep(kt, s1, s0); kstep(kt + 1, s0, s1); }
+            if (kt < KT) kstep(kt, s1, s0);
+        } else {
+            for (; kt < KT; ++kt) {
+                kstep(kt, smem + nxt * STAGE_BYTES, smem + cur * STAGE_BYTES);
+                cur = cur + 1 == NS ? 0 : cur + 1;
+                nxt = nxt + 1 == NS ? 0 : nxt + 1;
+            }
+        }
     }
     unsigned long long t_loop_end = 0;
     if (DIAG) t_loop_end = stamp();
@@ -495,7 +520,8 @@ constexpr size_t conv_lds_bytes()
     return lds0 > ldso ? lds0 : ldso;
 }
 
-hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
+template <int EB>
+static hipError_t launch_conv_diag_t(const ConvArgs &a, hipStream_t s)
 {
     // diagnostic instantiation of ONE configuration (p176c128_s2, uniform tap)
     constexpr int WP = 1, WC = 4, TP = 11, TC = 2, NS = 2, BK = 64;
@@ -504,10 +530,11 @@ hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s)
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     static bool done = false;
-    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
+hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s) { return a.in_dt == DT_FP8 ? launch_conv_diag_t<1>(a, s) : launch_conv_diag_t<2>(a, s); }
 
 // ---------------------------------------------------------------------------------------------
 // First layer (3x3, stride 1, 3 real input channels padded to 8): HBM-bound (it writes N*H*W*Cout bf16), K is only
@@ -630,7 +657,8 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
     X(24, 1, 4, 7, 2, 2, 64, 0)                                                                            \
     X(25, 1, 4, 11, 2, 2, 32, 0) X(26, 2, 2, 4, 2, 2, 32, 0)  X(27, 4, 1, 4, 2, 2, 32, 0)  X(28, 4, 1, 4, 4, 2, 32, 0)  \
     X(29, 2, 2, 2, 2, 2, 32, 0)  X(30, 2, 2, 2, 4, 2, 32, 0)                                                \
-    X(31, 1, 8, 11, 2, 2, 64, 4) X(32, 1, 8, 11, 2, 2, 64, 0)
+    X(31, 1, 8, 11, 2, 2, 64, 4) X(32, 1, 8, 11, 2, 2, 64, 0)                                              \
+    X(33, 1, 4, 11, 2, 3, 64, 0) X(34, 1, 4, 6, 2, 3, 64, 0)
 
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl},
@@ -705,7 +733,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     X(0, 2, 2, 4, 4, 2, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(4, 4, 1, 4, 2, 2, 64, 0)  X(6, 2, 2, 4, 2, 2, 64, 0)    \
     X(8, 4, 1, 4, 4, 2, 64, 0)  X(12, 2, 4, 4, 4, 2, 64, 0) X(14, 2, 2, 2, 2, 2, 64, 0) X(16, 1, 4, 11, 2, 2, 64, 0)  \
     X(17, 1, 4, 11, 4, 2, 64, 0) X(19, 1, 4, 10, 2, 2, 64, 0) X(20, 1, 4, 12, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0) \
-    X(32, 1, 8, 11, 2, 2, 64, 0)
+    X(32, 1, 8, 11, 2, 2, 64, 0) X(31, 1, 8, 11, 2, 2, 64, 4) X(33, 1, 4, 11, 2, 3, 64, 0) X(34, 1, 4, 6, 2, 3, 64, 0)
 bool conv_cfg_fp8_ok(int cfg)
 {
     switch (cfg) {
