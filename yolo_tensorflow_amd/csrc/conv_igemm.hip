@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_loader = NL == 0 || wave_id >= NC;          // wave-uniform role
-    const bool is_consumer = wave_id < NC;
+    const bool is_consumer = NL == 0 || wave_id < NC;
     const int wid = NL > 0 ? (wave_id >= NC ? wave_id - NC : 0) : wave_id;   // index among the loading waves
     const int wpi = wave_id % WP, wci = (wave_id / WP) % WC;
 
@@ -188,8 +188,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] : OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(dx + i * NW * 1024), 16, vo, soff, 0, 0);
             }
+            // branch-free cursor update (a branch here would split the K-step into basic blocks and keep the scheduler
+            // from placing these loads between the MFMAs)
             s_kb += BKE;
-            if (s_kb >= a.Cin_pad) { s_kb = 0; ++s_tap; if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; } }
+            const int w1 = s_kb >= a.Cin_pad ? 1 : 0;
+            s_kb = w1 ? 0 : s_kb; s_tap += w1; s_kw += w1;
+            const int w2 = s_kw == a.ksize ? 1 : 0;
+            s_kw = w2 ? 0 : s_kw; s_kh += w2;
         } else {
             int kh = 0, kw = 0;
             if (a.ksize == 3) { kh = (v_tap * 11) >> 5; kw = v_tap - kh * 3; }
@@ -217,6 +222,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = a.Kpad / BKE;
+    // SPREAD: place one LDS-DMA of the next stage behind every MFMA group instead of issuing the whole stage first
+    // (possible when the loads sit in the MFMAs' basic block: every wave loads, scalar tap cursor).  Measured A/B on one
+    // MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms) and fp8 (2.39 vs 2.34 ms) -- a DMA
+    // blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe holds no queue to ride it out.
+    constexpr bool SPREAD = false;
     constexpr int D = NS - 1;                  // prefetch distance in K-steps
 #pragma unroll
     for (int t = 0; t < D; ++t)
@@ -243,13 +253,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // fragment read of each K-step, i.e. the loads just issued for the NEXT step were waited for before this step's
     // MFMAs) unless alias-scope metadata proves the DMA target and the read are different memory; restrict parameters
     // of an inlined function are what produces that metadata.
-    auto kstep = [&](int kt, char *__restrict__ fill, const char *__restrict__ sb) {
+    auto kstep = [&](int kt, char *__restrict__ fill, const char *__restrict__ sb, const bool LOAD) {
         const unsigned long long s0 = stamp();
         // K-step kt has landed once at most (D-1) younger K-steps' loads remain outstanding (in-order counter)
-        if (is_loader) { if (kt + D <= KT) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>(); }
+        if (is_loader) { if (LOAD) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>(); }
         block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
         const unsigned long long s1 = stamp();
-        if (kt + D < KT && is_loader) stage(fill);
+        if (LOAD && is_loader) stage(fill);
         const unsigned long long s2 = stamp();
         // Fragment reads are software-pipelined PD MFMA groups ahead and PINNED there with sched_group_barrier: left
         // alone the scheduler hoists every ds_read of the (half) step above the first MFMA and waits lgkmcnt(0), so
@@ -284,6 +294,9 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int j = 0; j < TP; ++j) {
                     if (j + PD < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                    // one LDS-DMA of the next stage behind each MFMA group: its ~60-cycle issue overlaps the MFMAs
+                    // already queued instead of preceding all of them
+                    if (SPREAD && LOAD && j < L) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 }
             }
         } else if (is_consumer) {
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                if (SPREAD && LOAD && (g & 1) && (g >> 1) < L) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
         }
         if (DIAG) {
@@ -336,11 +350,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         int kt = 0;
         if (NS == 2) {
             char *const s0 = smem, *const s1 = smem + STAGE_BYTES;
-            for (; kt + 1 < KT; kt += 2) { kstep(kt, s1, s0); kstep(kt + 1, s0, s1); }
-            if (kt < KT) kstep(kt, s1, s0);
+            const int KM = KT - D;              // K-steps that still have a later step to load for
+            for (; kt + 1 < KM; kt += 2) { kstep(kt, s1, s0, true); kstep(kt + 1, s0, s1, true); }
+            if (kt < KM) { kstep(kt, s1, s0, true); ++kt; }
+            for (; kt < KT; ++kt) kstep(kt, (kt & 1) ? s0 : s1, (kt & 1) ? s1 : s0, false);      // stage = kt & 1
         } else {
             for (; kt < KT; ++kt) {
-                kstep(kt, smem + nxt * STAGE_BYTES, smem + cur * STAGE_BYTES);
+                kstep(kt, smem + nxt * STAGE_BYTES, smem + cur * STAGE_BYTES, kt + D < KT);
                 cur = cur + 1 == NS ? 0 : cur + 1;
                 nxt = nxt + 1 == NS ? 0 : nxt + 1;
             }
