@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0       # dense e4m3 through v_mfma_*_f8f6f4 (same table)
 
 
 def cpu_baseline(cfg_txt, flat, budget_s=25.0):
@@ -66,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
+    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
+                    help="bf16 is BASELINE.json's headline configuration; fp8 is its config 5 (reported as a separate line)")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +91,8 @@ def main():
     B, G = args.batch, world
     max_out = 20
     stream = torch.cuda.current_stream(dev)
-    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
+    fp8 = args.dtype == "fp8"
+    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
                      device=local_rank, stream=stream.cuda_stream)
     eng.set_weights(flat)
     # this rank's shard of the global batch (weak scaling: B images per GPU), resident in HBM
@@ -103,7 +107,7 @@ def main():
     counts_all = torch.empty((B * G,), dtype=torch.int32, device=dev)
     eng.forward(images, want_detections=False)
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
-    tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_bf16.json" % (args.size, B))
+    tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, args.dtype))
     loaded = False
     if os.path.exists(tuned) and not args.retune:
         try:
@@ -158,7 +162,7 @@ def main():
         total_ms, conv_ms = eng.time_forward(B, 10, conv=True)
         traffic = None      # HBM bytes per forward of the conv launches, from the committed PMC passes (cannot be read in-process)
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if args.size == 416 and B == 32 and os.path.exists(tpath):
+        if args.size == 416 and B == 32 and not fp8 and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))["conv_hbm_bytes_per_forward"]
             except Exception:      # noqa: BLE001
@@ -168,16 +172,17 @@ def main():
         out = {
             "metric": "images_per_sec", "value": round(B * G * args.steps / elapsed, 2), "unit": "img/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "YOLOv3 %dx%d batch=%d per GPU, bf16: conv stack + head decode + threshold + TF-NMS%s"
-                                   % (args.size, args.size, B, " + RCCL all-gather of box records" if G > 1 else ""),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "YOLOv3 %dx%d batch=%d per GPU, %s: conv stack + head decode + threshold + TF-NMS%s"
+                                   % (args.size, args.size, B, "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "bf16",
+                                      " + RCCL all-gather of box records" if G > 1 else ""),
                        "global_batch": B * G, "input": "uint8 NHWC resident in HBM", "weights": "seeded synthetic darknet stream (seed 0)",
                        "parallelism": "dp%d" % G},
             "p50_ms_per_image": round(float(np.median(step_ms)) / B, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv_igemm_bf16 (75 launches/forward)", "flops_per_forward": flops,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4), "traffic": traffic,
+                         "kernel": "conv_igemm (75 launches/forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
         if G == 1 and not args.no_cpu_baseline:
