@@ -160,7 +160,7 @@ int yolo_synchronize(yolo_ctx *ctx);
  * keep_layers=1).  dims_out receives H,W,C.  Head (yolo/region) layers return the raw conv tensor. */
 int yolo_layer_output(yolo_ctx *ctx, int index, int n, float *out, size_t out_floats, int *dims_out);
 /* Times `iters` forwards of batch n on the context stream with HIP events:
- * total_ms = wall per forward; conv_ms = sum of the conv kernels' own durations per forward
+ * total_ms = wall per forward; conv_ms = the conv launches' share of it (all layers minus all-but-conv, bulk-timed)
  * (events around every conv launch, separate pass).  Either may be NULL. */
 int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *conv_ms);
 /* Per-layer kernel time (ms, averaged over iters) for batch n into ms_out[num_layers]. */

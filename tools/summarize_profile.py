@@ -17,12 +17,12 @@ def last_json(path):
     return json.loads(line) if line else None
 
 
-for name in ("bench.json", "bench_under_rocprof.json"):
+for name in ("bench.json", "bench_fp8.json", "bench_under_rocprof.json"):
     j = last_json(os.path.join(src, name))
     if j:
         json.dump(j, open(os.path.join(dst, "%s_%s" % (R, name)), "w"), indent=1)
 
-st = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
+st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True) or glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(dst, "%s_bench_kernel_stats.csv" % R))
 

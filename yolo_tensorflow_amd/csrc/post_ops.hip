@@ -98,6 +98,139 @@ __global__ __launch_bounds__(256) void k_decode_yolo(const DecodeArgs a, float *
     }
 }
 
+// wave-wide maximum on the vector ALU only (DPP row operations, no LDS traffic): lane 63 ends up with the maximum of all
+// 64 lanes, which is broadcast with a readlane
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+#define DPP_MAX(ctrl, rmask)                                                                                      \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false)))
+    DPP_MAX(0xB1, 0xF);      // quad_perm [1,0,3,2]
+    DPP_MAX(0x4E, 0xF);      // quad_perm [2,3,0,1]
+    DPP_MAX(0x124, 0xF);     // row_ror:4
+    DPP_MAX(0x128, 0xF);     // row_ror:8   -> every lane holds its row's (16 lanes) maximum
+    DPP_MAX(0x142, 0xA);     // row_bcast:15 into rows 1 and 3
+    DPP_MAX(0x143, 0xC);     // row_bcast:31 into rows 2 and 3
+#undef DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Same decode, one wave per grid CELL (all `na` boxes of a pixel = na*(5+C) <= 256 contiguous floats on both sides):
+// lane l owns channels l, l+64, l+128, l+192, so every load and store instruction is one fully coalesced 256-B run, the
+// index arithmetic is paid once per cell instead of once per box, and the per-box arg-max is a DPP max + one ballot.
+// The wave-per-box form above spent ~150 instructions per box (index math, two half-empty passes, 12 bpermutes) and
+// ran the 52x52 head at 2 TB/s.
+template <int R>
+__global__ __launch_bounds__(256) void k_decode_yolo_cell(const DecodeArgs a, float *scores, int *labels)
+{
+    const int attrs = 5 + a.classes, nch = a.na * attrs;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int gg = a.g * a.g;
+    const long total = (long)a.n * gg;
+    const int stride = a.img_size / a.g;
+    const float G = (float)a.g, S = (float)stride;
+    // per-lane channel decomposition, constant over the cells
+    int an_[R], k_[R]; bool ok_[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        ok_[r] = ch < nch;
+        an_[r] = ch / attrs; k_[r] = ch - an_[r] * attrs;
+    }
+    bool spec_[R]; unsigned long long seen = 0; bool merged = true;      // geometry lanes; mergeable when no lane repeats
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        spec_[r] = ok_[r] && k_[r] < 4;
+        const unsigned long long m = __ballot(spec_[r]);
+        merged = merged && !(seen & m); seen |= m;
+    }
+    // the next cell's loads are issued before this cell is decoded (one cell of prefetch per wave: the head tensor was
+    // written by the previous kernel and comes from the Infinity Cache / HBM, ~1-2 us away)
+    float xn[R];
+    if (wave < total) {
+        const float *src = a.raw + (size_t)wave * a.raw_stride;
+#pragma unroll
+        for (int r = 0; r < R; ++r) xn[r] = ok_[r] ? src[lane + 64 * r] : 0.f;
+    }
+    for (long p = wave; p < total; p += nwaves) {
+        const unsigned up = (unsigned)__builtin_amdgcn_readfirstlane((int)p);
+        const int b = (int)(up / (unsigned)gg), cell = (int)(up - (unsigned)b * gg);
+        const int cy = cell / a.g, cx = cell - cy * a.g;
+        const size_t row0 = (size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na;
+        float *dst = a.det + row0 * attrs;
+        float x[R], v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = xn[r];
+        if (p + nwaves < total) {
+            const float *src = a.raw + (size_t)(p + nwaves) * a.raw_stride;
+#pragma unroll
+            for (int r = 0; r < R; ++r) xn[r] = ok_[r] ? src[lane + 64 * r] : 0.f;
+        }
+        // 4 of every (5+C) channels are box geometry and need the full-precision expf; the rest take the hardware-rate
+        // sigmoid.  The geometry lanes of the R registers are (normally) disjoint lane sets, so they are merged into ONE
+        // register and the expensive divergent branch runs once per cell instead of once per register.
+        float xs = 0.f; int ks = 4, ans = 0;
+        if (merged) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (spec_[r]) { xs = x[r]; ks = k_[r]; ans = an_[r]; }
+            float vs = 0.f;
+            if (ks < 2) {
+                const float sg = sigmoidf_(xs) + (float)(ks == 0 ? cx : cy);
+                vs = a.mode == 0 ? sg / G : sg * S;
+            } else if (ks < 4) {
+                const float e = expf(xs) * a.anchors[2 * ans + (ks - 2)];       // anchors pre-divided by stride on the host
+                vs = a.mode == 0 ? e / G : e * S;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                v[r] = spec_[r] ? vs : sigmoid_fast(x[r]);
+                if (ok_[r]) dst[lane + 64 * r] = v[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int k = k_[r];
+                if (k < 2) {
+                    const float sg = sigmoidf_(x[r]) + (float)(k == 0 ? cx : cy);
+                    v[r] = a.mode == 0 ? sg / G : sg * S;
+                } else if (k < 4) {
+                    const float e = expf(x[r]) * a.anchors[2 * an_[r] + (k - 2)];
+                    v[r] = a.mode == 0 ? e / G : e * S;
+                } else {
+                    v[r] = sigmoid_fast(x[r]);
+                }
+                if (ok_[r]) dst[lane + 64 * r] = v[r];
+            }
+        }
+        if (!scores) continue;
+        for (int an = 0; an < a.na; ++an) {
+            // objectness of box `an` sits at channel an*attrs + 4
+            const int oc = an * attrs + 4, ol = oc & 63, orr = oc >> 6;
+            float ov = v[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) ov = orr == r ? v[r] : ov;
+            const float obj = __shfl(ov, ol);
+            float sc[R]; float best = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                sc[r] = (ok_[r] && an_[r] == an && k_[r] >= 5) ? obj * v[r] : -INFINITY;
+                best = fmaxf(best, sc[r]);
+            }
+            best = wave_max_dpp(best);
+            // first (lowest class index = lowest channel) position holding the maximum: registers in ascending order,
+            // lowest lane inside a register
+            int label = 0x7fffffff;
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const unsigned long long m = __ballot(sc[r] == best);
+                if (m) label = (int)__builtin_ctzll(m) + 64 * r - an * attrs - 5;
+            }
+            if (lane == 0) { scores[row0 + an] = best; labels[row0 + an] = label; }
+        }
+    }
+}
+
 // ---- D2: V2 `decode` (V2/decode.py:13-47): sigmoid xy/obj, exp wh, softmax classes; stored as
 //      (bx, by, bw, bh, obj, cls...) normalised; corners are formed at selection time ----
 __global__ void k_decode_region(const DecodeArgs a)
@@ -136,6 +269,14 @@ hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStr
                                   scores + (size_t)b * a.rows_total + a.row_off, labels + (size_t)b * a.rows_total + a.row_off, s);
         }
     } else {
+        const int nch = a.na * (5 + a.classes);
+        if (nch <= 256 && a.raw_stride >= nch) {                   // one wave per cell (every shipped topology)
+            size_t cells = (size_t)a.n * a.g * a.g;
+            size_t blocks = (cells + 3) / 4; if (blocks > 256 * 8) blocks = 256 * 8;    // persistent: 8 workgroups per CU
+            if (nch <= 128) hipLaunchKernelGGL(k_decode_yolo_cell<2>, dim3((unsigned)blocks), dim3(256), 0, s, a, scores, labels);
+            else hipLaunchKernelGGL(k_decode_yolo_cell<4>, dim3((unsigned)blocks), dim3(256), 0, s, a, scores, labels);
+            return hipGetLastError();
+        }
         size_t total = (size_t)a.n * a.g * a.g * a.na;             // four boxes per wave per step, grid-stride
         if (5 + a.classes > 128) return hipErrorInvalidValue;
         size_t blocks = (total + 15) / 16; if (blocks > (1u << 20)) blocks = 1u << 20;   // one step per wave: latency-bound otherwise
