@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 else { v[0] = acc[i][j][0] + bv.x; v[1] = acc[i][j][1] + bv.y; v[2] = acc[i][j][2] + bv.z; v[3] = acc[i][j][3] + bv.w; }
                 if (a.act == ACT_LEAKY) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
                 }
                 uint2 pk;
                 pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 else { v[0] = acc[i][j][0] + bv.x; v[1] = acc[i][j][1] + bv.y; v[2] = acc[i][j][2] + bv.z; v[3] = acc[i][j][3] + bv.w; }
                 if (a.act == ACT_LEAKY) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
                 }
                 float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
                 if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
                     float v[4] = {acc[i][0] + bv[i].x, acc[i][1] + bv[i].y, acc[i][2] + bv[i].z, acc[i][3] + bv[i].w};
                     if (a.act == ACT_LEAKY)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
                     uint2 pk;
                     pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
                     pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);

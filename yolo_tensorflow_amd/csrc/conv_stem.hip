@@ -1,0 +1,224 @@
+// Fused network stem for gfx950: conv 3x3/s1 (3 -> C0 = 32 channels) immediately consumed by conv 3x3/s2 (C0 -> C1 = 64),
+// both with BN folded, bias and leaky/linear epilogues -- darknet-53's first two layers (V3/yolo_v3.py:15-24 `darknet53`,
+// DN cfg layers 0-1).  Run separately they are pure HBM traffic: layer 0 writes N*S*S*32 bf16 (354 MB at 416^2, batch 32)
+// that layer 1 reads straight back.  Here a workgroup produces an 8 x 16 tile of layer-1 pixels: it first computes the
+// 17 x 33 layer-0 pixels that tile needs into LDS (bf16, exactly the values the unfused layer would have stored, zeros
+// where layer 1 pads), then contracts them with the layer-1 filters held in registers.  HBM sees the 8-channel image
+// once and the layer-1 output once.
+//
+//   input    the 19 x 35 input pixels (16 B each) a tile needs are gathered into LDS by LDS-DMA one tile AHEAD (double
+//            buffered), so no wave ever waits on global-memory latency inside a tile; image borders are zero-filled
+//            by the buffer range check.
+//   phase A  one 16-pixel group per step and wave: a lane's B fragment for K-group (kk, lq) is the 16-byte channel
+//            vector of ONE input pixel (tap kk*4+lq), one ds_read_b128; 6 MFMAs; the 4 channels a lane ends up with go
+//            to LDS as one ds_write_b64.  LDS pixel pitch is 80 B: with layer 1's stride-2 access
+//            the 16 lanes of every ds_read_b128 lane group then fall on 16 distinct 16-B bank slots.
+//   phase B  wave w (of 8) owns output row w of the tile (16 pixels) x 64 channels: per tap one ds_read_b128
+//            (K-step = the tap's 32 channels) feeding 4 MFMAs against register-resident filters.
+//   epilogue through LDS so that the global stores are 16 B per lane, whole 128-B pixel rows.
+// Workgroups are persistent (one 8-wave workgroup per CU) so the 168 VGPRs of filter fragments are loaded once per wave.
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t stem_bf16(float f)
+{
+    __bf16 b = (__bf16)f;
+    return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+
+constexpr int ST_TH = 8, ST_TW = 16;                 // layer-1 output tile
+constexpr int ST_LH = 2 * ST_TH + 1, ST_LW = 2 * ST_TW + 1;   // layer-0 pixels it needs: 17 x 33
+constexpr int ST_NPIX = ST_LH * ST_LW;               // 561
+constexpr int ST_GROUPS = (ST_NPIX + 15) / 16;       // 36
+constexpr int ST_PITCH = 80;                         // LDS bytes per layer-0 pixel (32 bf16 + 16 B pad)
+constexpr int ST_L0_BYTES = ST_GROUPS * 16 * ST_PITCH;        // 46080
+constexpr int ST_OPITCH = 64 * 2 + 16;               // staged layer-1 tile: 64 bf16 + pad
+constexpr int ST_OUT_BYTES = ST_TH * ST_TW * ST_OPITCH;       // 18432
+
+
+constexpr int ST_NW = 8;                             // waves per workgroup == ST_TH
+typedef __attribute__((address_space(3))) void st_lds_void;
+constexpr int ST_IH = ST_LH + 2, ST_IW = ST_LW + 2;          // input pixels a tile needs: 19 x 35
+constexpr int ST_INPIX = ST_IH * ST_IW;                      // 665
+constexpr int ST_INCHUNKS = (ST_INPIX + 63) / 64;            // 64-pixel LDS-DMA pieces: 11
+constexpr int ST_IN_BYTES = ST_INCHUNKS * 1024 + 16;         // + one 16-B slot of zeros (taps 9..11 of the K padding)
+
+__global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- filters and biases, once per wave ----
+    bf16x8 fw0[2][3], fw1[4][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            fw0[i][kk] = *(const bf16x8 *)((const bf16_t *)a.w0 + (size_t)(i * 16 + l15) * a.Kpad0 + (kk * 4 + lq) * 8);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            fw1[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w1 + (size_t)(ct * 16 + l15) * a.Kpad1 + t * 32 + lq * 8);
+    float4 b0v[2], b1v[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b0v[i] = *(const float4 *)(a.b0 + i * 16 + lq * 4);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b1v[ct] = *(const float4 *)(a.b1 + ct * 16 + lq * 4);
+
+    const int tiles_x = (a.Wo + ST_TW - 1) / ST_TW, tiles_y = (a.Ho + ST_TH - 1) / ST_TH;
+    const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
+    // the image is read through a buffer descriptor: an out-of-range offset makes the LDS-DMA write zeros (the padding)
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0x80000000u, 0x00020000);
+
+    // gather the 19 x 35 input pixels (16 B each) of `tile` into `dst`: lane-linear 64-pixel pieces, piece c by wave c % 8
+    auto fetch = [&](int tile, char *dst) {
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int iy0 = 2 * ty * ST_TH - 2, ix0 = 2 * tx * ST_TW - 2;
+#pragma unroll
+        for (int k = 0; k < (ST_INCHUNKS + ST_NW - 1) / ST_NW; ++k) {
+            const int c = wave + ST_NW * k;
+            if (c < ST_INCHUNKS) {
+                const int q = c * 64 + lane;
+                const int ry = (q * 1873) >> 16;                 // q / 35 for q < 704
+                const int rxx = q - ry * ST_IW;
+                const int iy = iy0 + ry, ix = ix0 + rxx;
+                const bool ok = q < ST_INPIX && tile < ntiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.in_stride) * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (st_lds_void *)(dst + c * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    // One tile.  Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling
+    // `in_next` cannot alias the reads below, instead of waiting vmcnt(0) before the first ds_read after it.
+    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur,
+                       char *__restrict__ l0, char *__restrict__ lo) {
+        fetch(next_tile, in_next);                               // lands during this tile's two phases
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;          // layer-0 coordinates of LDS pixel (0, 0)
+
+        // ---- phase A: layer-0 pixels of this tile -> LDS; a lane's B fragment (kk, lq) = input pixel of tap kk*4+lq ----
+        constexpr int ROUNDS = (ST_GROUPS + ST_NW - 1) / ST_NW;
+        // The loop stays rolled: unrolled, the per-round offsets are hoisted out of the tile loop and spill (168 VGPRs hold
+        // filters).  (Reading round j+1's fragments during round j was tried: +10 % time, the register copies cost more
+        // than the exposed LDS latency with two waves per SIMD.)
+#pragma unroll 1
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int g = wave + ST_NW * j;
+            if (g < ST_GROUPS) {
+                const int idx = g * 16 + l15;
+                const int ly = (idx * 1986) >> 16;               // idx / 33 for idx < 576
+                const int lx = idx - ly * ST_LW;
+                const bool inside = idx < ST_NPIX && (unsigned)(gy0 + ly) < (unsigned)a.H && (unsigned)(gx0 + lx) < (unsigned)a.W;
+                bf16x8 fx[3];
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int tap = kk * 4 + lq;
+                    const int kh = (tap * 11) >> 5, kw = tap - kh * 3;
+                    // layer-0 pixel (ly, lx) sits at input-region pixel (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw)
+                    const int q = (ly + kh) * ST_IW + lx + kw;
+                    const int off = (tap < 9 && idx < ST_NPIX) ? q * 16 : ST_INCHUNKS * 1024;      // else the zero slot
+                    fx[kk] = *(const bf16x8 *)(in_cur + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[i][kk], fx[kk], acc, 0, 0, 0);
+                    float v[4] = {acc[0] + b0v[i].x, acc[1] + b0v[i].y, acc[2] + b0v[i].z, acc[3] + b0v[i].w};
+                    if (a.act0 == ACT_LEAKY)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);       // == v > 0 ? v : 0.1 v, two VALU ops
+                    uint2 pk;
+                    pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
+                    pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
+                    if (!inside) pk = uint2{0, 0};               // layer 1's zero padding, and the unused tail rows
+                    *(uint2 *)(l0 + idx * ST_PITCH + (i * 16 + lq * 4) * 2) = pk;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes are done
+        __builtin_amdgcn_s_barrier();
+
+        // ---- phase B: 16 layer-1 pixels (tile row `wave`) x 64 channels per wave ----
+        f32x4 acc1[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char *xb = l0 + ((2 * wave) * ST_LW + 2 * l15) * ST_PITCH + lq * 16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - kh * 3;
+            const bf16x8 x = *(const bf16x8 *)(xb + (kh * ST_LW + kw) * ST_PITCH);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[ct][t], x, acc1[ct], 0, 0, 0);
+        }
+        // ---- epilogue: bias + activation -> bf16 -> LDS -> 16-B stores ----
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float v[4] = {acc1[ct][0] + b1v[ct].x, acc1[ct][1] + b1v[ct].y, acc1[ct][2] + b1v[ct].z, acc1[ct][3] + b1v[ct].w};
+            if (a.act1 == ACT_LEAKY)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);       // == v > 0 ? v : 0.1 v, two VALU ops
+            uint2 pk;
+            pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
+            pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = pk;
+        }
+        // staged tile complete, every wave done with the layer-0 tile, and the next tile's input has landed
+        __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < ST_TH * ST_TW * 8 / (64 * ST_NW); ++it) {
+            const int c = tid + it * 64 * ST_NW;
+            const int px = c >> 3, chunk = c & 7;
+            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+            if (oy < a.Ho && ox < a.Wo)
+                *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) = *(const uint4 *)(lo + px * ST_OPITCH + chunk * 16);
+        }
+        // the next tile's phase A writes l0 (free since the barrier above) and its staged-tile writes come after its own
+        // first barrier, by which time every thread has finished the reads of `lo` just above
+    };
+
+    char *const inb0 = smem, *const inb1 = smem + ST_IN_BYTES;
+    char *const l0 = smem + 2 * ST_IN_BYTES, *const lo = l0 + ST_L0_BYTES;
+    if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile, inb0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo);
+        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo);
+    }
+#endif
+}
+
+bool conv_stem_ok(const StemArgs &a)
+{
+    return a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&
+           a.Ho == (a.H + 2 - 3) / 2 + 1 && a.Wo == (a.W + 2 - 3) / 2 + 1;
+}
+
+hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
+{
+    if (!conv_stem_ok(a)) return hipErrorInvalidValue;
+    static bool done = false;
+    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv_stem_c32_c64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
+    long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
+    hipLaunchKernelGGL(conv_stem_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    return hipGetLastError();
+}

@@ -70,6 +70,17 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
 bool conv_cfg_fp8_ok(int cfg);
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
+// fused stem: conv 3x3/s1 (3 -> 32) + conv 3x3/s2 (32 -> 64), bf16 (conv_stem.hip)
+struct StemArgs {
+    const void *in; int in_stride;            // [N,H,W,8] bf16 image (3 real channels)
+    const void *w0; const float *b0; int Kpad0, C0, act0;    // layer 0: [C0 pad][Kpad0], k = tap*8 + ci
+    const void *w1; const float *b1; int Kpad1, C1, act1;    // layer 1: [C1 pad][Kpad1], k = tap*C0 + ci
+    void *out; int out_stride;                // [N,Ho,Wo,C1] bf16
+    int N, H, W, Ho, Wo;
+    const void *zeros;
+};
+bool conv_stem_ok(const StemArgs &a);
+hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s);
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 

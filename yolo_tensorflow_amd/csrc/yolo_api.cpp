@@ -40,6 +40,7 @@ struct Layer {
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
+    bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
     // shortcut/route bookkeeping
     bool noop = false;                   // output is an alias / was produced by someone else
     std::vector<int> copy_inputs;        // route inputs that must be copied (could not be placed)
@@ -265,6 +266,14 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1) { P.residual_from = L.in[1]; L.noop = true; }
         }
     }
+    // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
+    if (c->dtype == YOLO_BF16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM")) {
+        const Layer &A = c->layers[0], &B = c->layers[1];
+        if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
+            A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1) {
+            c->layers[0].stem_skip = true; c->layers[1].stem = true;
+        }
+    }
     // storage assignment: st_of[i] = storage holding layer i's output
     std::vector<int> place_route(NL, -1), place_off(NL, 0);
     for (int i = 0; i < NL; ++i) {
@@ -298,6 +307,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.type == L_YOLO || L.type == L_REGION) { L.noop = true; L.storage = c->layers[i - 1].storage; L.ch_off = c->layers[i - 1].ch_off; continue; }
         if (L.type == L_ROUTE && L.in.size() == 1) { L.noop = true; int j = L.in[0]; if (j < 0) return fail(c, YOLO_ERR_UNSUPPORTED, "route to network input"); L.storage = c->layers[j].storage; L.ch_off = c->layers[j].ch_off; continue; }
         if (L.type == L_ROUTE) continue;
+        if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
         else L.storage = new_storage(roundup(L.C, c->gran()), c->act_dt(), (size_t)c->max_batch * L.H * L.W, c->keep_layers);
@@ -317,7 +327,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         Layer &L = c->layers[i];
         if (L.storage < 0) continue;
         if (!L.noop) { Storage &s = c->storages[L.storage]; s.def = std::min(s.def, i); s.last = std::max(s.last, i); }
-        for (int j : L.in) if (j >= 0) { Storage &s = c->storages[c->layers[j].storage]; s.last = std::max(s.last, i); }
+        for (int j : L.in) if (j >= 0 && c->layers[j].storage >= 0) { Storage &s = c->storages[c->layers[j].storage]; s.last = std::max(s.last, i); }
         if (L.type == L_CONV && L.residual_from >= 0) { Storage &s = c->storages[c->layers[L.residual_from].storage]; s.last = std::max(s.last, i); }
     }
     // greedy pooled assignment
@@ -350,6 +360,7 @@ int allocate(yolo_ctx *c)
         HIPCK(c, hipMemsetAsync(c->phys[i], 0, c->phys_bytes[i] + 256, c->stream));
     }
     for (auto &L : c->layers) {
+        L.out.n = c->max_batch; L.out.h = L.H; L.out.w = L.W; L.out.c = L.C;      // geometry even when nothing is stored
         if (L.storage < 0) continue;
         Storage &s = c->storages[L.storage];
         if (s.phys < 0) return fail(c, YOLO_ERR_STATE, "internal: storage without buffer");
@@ -410,6 +421,17 @@ int run_layer(yolo_ctx *c, int i, int n)
     auto nview = [&](TView v) { v.n = n; return v; };
     switch (L.type) {
     case L_CONV: {
+        if (L.stem_skip) break;
+        if (L.stem) {
+            const Layer &A = c->layers[0];
+            StemArgs t; memset(&t, 0, sizeof t);
+            t.in = c->input.ptr; t.in_stride = c->input.stride;
+            t.w0 = A.d_w; t.b0 = A.d_b; t.Kpad0 = A.kpad; t.C0 = A.filters; t.act0 = A.act;
+            t.w1 = L.d_w; t.b1 = L.d_b; t.Kpad1 = L.kpad; t.C1 = L.filters; t.act1 = L.act;
+            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros;
+            HIPCK(c, launch_conv_stem(t, s));
+            break;
+        }
         ConvArgs a = conv_args(c, L, n);
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
@@ -705,7 +727,9 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
     for (auto &L : c->layers) if (L.type == L_CONV) {
         TView in = view_of(c, L.in[0]);
         const double ie = (double)dt_size(L.in_dt), oe = (double)dt_size(L.out.dt);
-        b += (double)n * in.h * in.w * L.cin * ie + (double)n * L.H * L.W * L.filters * oe + (double)L.filters * L.cin * L.size * L.size * ie;
+        if (!L.stem) b += (double)n * in.h * in.w * L.cin * ie;                          // the fused stem keeps layer 0's output in LDS
+        if (!L.stem_skip) b += (double)n * L.H * L.W * L.filters * oe;
+        b += (double)L.filters * L.cin * L.size * L.size * ie;
     }
     return b;
 }
@@ -897,13 +921,14 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
+        if (L.stem || L.stem_skip) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
@@ -919,7 +944,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         // a configuration a layer cannot launch (LDS / 2 GiB window) must not abort the pass: probe once
         for (int i = 0; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type != L_CONV || L.tile_cfg != cfg) continue;
+            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip) continue;
             ConvArgs a = conv_args(c, L, n);
             hipError_t e = a.in_dt == DT_FP8 ? launch_conv_fp8(a, cfg, c->stream) : launch_conv_bf16(a, cfg, c->stream);
             if (e != hipSuccess) { (void)hipGetLastError(); L.tile_cfg = fallback[i]; }
@@ -927,17 +952,17 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         int r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
         for (int i = 0; i < NL; ++i) {
             const Layer &L = c->layers[i];
-            if (L.type == L_CONV && L.tile_cfg == cfg) score[shape_key(L)][cfg] += ms[i];
+            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip) score[shape_key(L)][cfg] += ms[i];
         }
         if (getenv("YOLO_TUNE_VERBOSE")) {
             std::map<std::string, double> seen;
-            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
+            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
             for (auto &kv : seen) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms (sum over the layers of this shape, in situ)\n", kv.first.c_str(), cfg, conv_cfg_name(cfg), kv.second);
         }
     }
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type != L_CONV) continue;
+        if (L.type != L_CONV || L.stem || L.stem_skip) continue;
         auto it = score.find(shape_key(L));
         int best = fallback[i]; double bt = 1e30;
         if (it != score.end()) for (auto &kv : it->second) if (kv.second < bt) { bt = kv.second; best = kv.first; }
