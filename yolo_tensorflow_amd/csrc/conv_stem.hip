@@ -16,6 +16,8 @@
 //   phase B  wave w (of 8) owns output row w of the tile (16 pixels) x 64 channels: per tap one ds_read_b128
 //            (K-step = the tap's 32 channels) feeding 4 MFMAs against register-resident filters.
 //   epilogue through LDS so that the global stores are 16 B per lane, whole 128-B pixel rows.
+// Optional tail: the 1x1 conv 64 -> 32 that follows (darknet-53 layer 2) runs on the staged layer-1 tile before it
+// leaves LDS, so that layer never re-reads its 177 MB input.
 // Workgroups are persistent (one 8-wave workgroup per CU) so the 168 VGPRs of filter fragments are loaded once per wave.
 #include "kernels.h"
 
@@ -44,6 +46,11 @@ constexpr int ST_IH = ST_LH + 2, ST_IW = ST_LW + 2;          // input pixels a t
 constexpr int ST_INPIX = ST_IH * ST_IW;                      // 665
 constexpr int ST_INCHUNKS = (ST_INPIX + 63) / 64;            // 64-pixel LDS-DMA pieces: 11
 constexpr int ST_IN_BYTES = ST_INCHUNKS * 1024 + 16;         // + one 16-B slot of zeros (taps 9..11 of the K padding)
+constexpr int ST_O2PITCH = 32 * 2 + 16;                      // staged tail tile: 32 bf16 + pad
+constexpr int ST_OUT2_BYTES = ST_TH * ST_TW * ST_O2PITCH;    // 10240
+constexpr int ST_W2_BYTES = 32 * 64 * 2;                     // tail filters [32][64] bf16, kept in LDS (no registers left)
+constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
+                                                             // would make hipcc wait vmcnt(0) and drain the input prefetch
 
 __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a)
 {
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
     // One tile.  Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling
     // `in_next` cannot alias the reads below, instead of waiting vmcnt(0) before the first ds_read after it.
     auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur,
-                       char *__restrict__ l0, char *__restrict__ lo) {
+                       char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2) {
         fetch(next_tile, in_next);                               // lands during this tile's two phases
         const int n = tile / per_img, tr = tile - n * per_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
@@ -183,20 +190,60 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             if (oy < a.Ho && ox < a.Wo)
                 *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) = *(const uint4 *)(lo + px * ST_OPITCH + chunk * 16);
         }
-        // the next tile's phase A writes l0 (free since the barrier above) and its staged-tile writes come after its own
-        // first barrier, by which time every thread has finished the reads of `lo` just above
+        if (a.w2) {
+            // ---- tail: 1x1 conv 64 -> 32 on the staged layer-1 tile (its bf16 values, exactly what a separate launch
+            //      would have re-read from HBM): wave w = tile row w, 2 channel tiles x 2 K-steps ----
+            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 x = *(const bf16x8 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 w = *(const bf16x8 *)(lw2 + ((i * 16 + l15) * 64 + (kk * 4 + lq) * 8) * 2);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc2[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 bv = *(const float4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4);
+                float v[4] = {acc2[i][0] + bv.x, acc2[i][1] + bv.y, acc2[i][2] + bv.z, acc2[i][3] + bv.w};
+                if (a.act2 == ACT_LEAKY)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
+                uint2 pk;
+                pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
+                pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
+                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = pk;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            {
+                const int px = tid >> 2, chunk = tid & 3;        // 128 pixels x 4 pieces of 16 B
+                const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+                if (oy < a.Ho && ox < a.Wo)
+                    *(uint4 *)((bf16_t *)a.out2 + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out2_stride + chunk * 8) = *(const uint4 *)(lo2 + px * ST_O2PITCH + chunk * 16);
+            }
+        }
+        // the next tile's phase A writes l0 (free since the first barrier of the epilogue) and its staged-tile writes come
+        // after its own first barrier, by which time every thread has finished the reads of `lo` / `lo2` above
     };
 
     char *const inb0 = smem, *const inb1 = smem + ST_IN_BYTES;
-    char *const l0 = smem + 2 * ST_IN_BYTES, *const lo = l0 + ST_L0_BYTES;
+    char *const l0 = smem + 2 * ST_IN_BYTES, *const lo = l0 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
+    if (a.w2)                                                    // tail filters -> LDS, 16 B per thread (256 pieces)
+        if (tid < ST_W2_BYTES / 16) {
+            const int row = tid >> 3, piece = tid & 7;
+            *(uint4 *)(lw2 + row * 128 + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
+            if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
+        }
     if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile, inb0);
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo);
-        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo);
+        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo, lo2, lw2);
+        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo, lo2, lw2);
     }
 #endif
 }
@@ -204,14 +251,15 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 bool conv_stem_ok(const StemArgs &a)
 {
     return a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&
-           a.Ho == (a.H + 2 - 3) / 2 + 1 && a.Wo == (a.W + 2 - 3) / 2 + 1;
+           a.Ho == (a.H + 2 - 3) / 2 + 1 && a.Wo == (a.W + 2 - 3) / 2 + 1 &&
+           (!a.w2 || (a.C2 == 32 && a.Kpad2 >= 64 && a.out2 && (a.out2_stride % 8) == 0 && a.out2_stride >= 32));
 }
 
 hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
     static bool done = false;
-    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES;
+    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES;
     if (!done) {
         hipError_t e = hipFuncSetAttribute((const void *)conv_stem_c32_c64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

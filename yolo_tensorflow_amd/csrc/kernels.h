@@ -76,6 +76,9 @@ struct StemArgs {
     const void *w0; const float *b0; int Kpad0, C0, act0;    // layer 0: [C0 pad][Kpad0], k = tap*8 + ci
     const void *w1; const float *b1; int Kpad1, C1, act1;    // layer 1: [C1 pad][Kpad1], k = tap*C0 + ci
     void *out; int out_stride;                // [N,Ho,Wo,C1] bf16
+    // optional tail: a 1x1/s1 conv C1 -> C2 = 32 on the freshly produced layer-1 tile (darknet-53 layer 2); w2 == nullptr: none
+    const void *w2; const float *b2; int Kpad2, C2, act2;    // [C2 pad][Kpad2], k = ci
+    void *out2; int out2_stride;              // [N,Ho,Wo,C2] bf16
     int N, H, W, Ho, Wo;
     const void *zeros;
 };

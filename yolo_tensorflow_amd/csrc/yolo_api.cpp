@@ -41,6 +41,7 @@ struct Layer {
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
+    bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     // shortcut/route bookkeeping
     bool noop = false;                   // output is an alias / was produced by someone else
     std::vector<int> copy_inputs;        // route inputs that must be copied (could not be placed)
@@ -272,6 +273,11 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
             A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1) {
             c->layers[0].stem_skip = true; c->layers[1].stem = true;
+            if (NL >= 3) {
+                const Layer &T = c->layers[2];
+                if (T.type == L_CONV && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1)
+                    c->layers[2].stem_tail = true;
+            }
         }
     }
     // storage assignment: st_of[i] = storage holding layer i's output
@@ -421,13 +427,17 @@ int run_layer(yolo_ctx *c, int i, int n)
     auto nview = [&](TView v) { v.n = n; return v; };
     switch (L.type) {
     case L_CONV: {
-        if (L.stem_skip) break;
+        if (L.stem_skip || L.stem_tail) break;
         if (L.stem) {
             const Layer &A = c->layers[0];
             StemArgs t; memset(&t, 0, sizeof t);
             t.in = c->input.ptr; t.in_stride = c->input.stride;
             t.w0 = A.d_w; t.b0 = A.d_b; t.Kpad0 = A.kpad; t.C0 = A.filters; t.act0 = A.act;
             t.w1 = L.d_w; t.b1 = L.d_b; t.Kpad1 = L.kpad; t.C1 = L.filters; t.act1 = L.act;
+            if (i + 1 < (int)c->layers.size() && c->layers[i + 1].stem_tail) {
+                const Layer &T = c->layers[i + 1];
+                t.w2 = T.d_w; t.b2 = T.d_b; t.Kpad2 = T.kpad; t.C2 = T.filters; t.act2 = T.act; t.out2 = T.out.ptr; t.out2_stride = T.out.stride;
+            }
             t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros;
             HIPCK(c, launch_conv_stem(t, s));
             break;
@@ -727,7 +737,7 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
     for (auto &L : c->layers) if (L.type == L_CONV) {
         TView in = view_of(c, L.in[0]);
         const double ie = (double)dt_size(L.in_dt), oe = (double)dt_size(L.out.dt);
-        if (!L.stem) b += (double)n * in.h * in.w * L.cin * ie;                          // the fused stem keeps layer 0's output in LDS
+        if (!L.stem && !L.stem_tail) b += (double)n * in.h * in.w * L.cin * ie;         // the fused stem keeps these inputs in LDS
         if (!L.stem_skip) b += (double)n * L.H * L.W * L.filters * oe;
         b += (double)L.filters * L.cin * L.size * L.size * ie;
     }
@@ -921,14 +931,14 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
-        if (L.stem || L.stem_skip) return false;                     // fused stem: nothing to choose
+        if (L.stem || L.stem_skip || L.stem_tail) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
@@ -944,7 +954,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         // a configuration a layer cannot launch (LDS / 2 GiB window) must not abort the pass: probe once
         for (int i = 0; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip) continue;
+            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip || L.stem_tail) continue;
             ConvArgs a = conv_args(c, L, n);
             hipError_t e = a.in_dt == DT_FP8 ? launch_conv_fp8(a, cfg, c->stream) : launch_conv_bf16(a, cfg, c->stream);
             if (e != hipSuccess) { (void)hipGetLastError(); L.tile_cfg = fallback[i]; }
@@ -952,17 +962,17 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         int r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
         for (int i = 0; i < NL; ++i) {
             const Layer &L = c->layers[i];
-            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip) score[shape_key(L)][cfg] += ms[i];
+            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip && !L.stem_tail) score[shape_key(L)][cfg] += ms[i];
         }
         if (getenv("YOLO_TUNE_VERBOSE")) {
             std::map<std::string, double> seen;
-            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
+            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
             for (auto &kv : seen) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms (sum over the layers of this shape, in situ)\n", kv.first.c_str(), cfg, conv_cfg_name(cfg), kv.second);
         }
     }
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type != L_CONV || L.stem || L.stem_skip) continue;
+        if (L.type != L_CONV || L.stem || L.stem_skip || L.stem_tail) continue;
         auto it = score.find(shape_key(L));
         int best = fallback[i]; double bt = 1e30;
         if (it != score.end()) for (auto &kv : it->second) if (kv.second < bt) { bt = kv.second; best = kv.first; }
