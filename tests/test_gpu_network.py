@@ -286,3 +286,20 @@ def test_detect_graph_replay_equals_eager(hiplib, v3_416):
     # a different argument re-captures transparently
     eng.detect_graph(d_img, boxes, counts, score_thr=0.6, iou_thr=0.5, max_out=max_out)
     eng.synchronize()
+
+
+@pytest.mark.parametrize("size", [96, 160, 224])
+def test_fused_plan_equals_layer_by_layer_plan(hiplib, size):
+    """The production plan (fused stem kernel for conv0+conv1+conv2, shortcuts folded into conv epilogues, pooled
+    buffers) gives bit-identical detections to the introspection plan that materialises every layer (keep_layers=1):
+    the fusions keep every intermediate rounding and the K order of the unfused kernels."""
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=3)
+    img = np.random.default_rng(size).integers(0, 256, (3, size, size, 3), dtype=np.uint8)
+    dets = []
+    for keep in (False, True):
+        eng = hiplib.Engine(txt, max_batch=3, dtype=hiplib.BF16, keep_layers=keep)
+        eng.set_weights(flat)
+        dets.append(eng.forward(img))
+        eng.close()
+    assert np.array_equal(dets[0], dets[1])
