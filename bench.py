@@ -182,7 +182,7 @@ def main():
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4), "traffic": traffic,
-                         "kernel": "conv_igemm (75 launches/forward)", "flops_per_forward": flops,
+                         "kernel": "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
         if G == 1 and not args.no_cpu_baseline:
