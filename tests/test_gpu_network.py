@@ -303,3 +303,39 @@ def test_fused_plan_equals_layer_by_layer_plan(hiplib, size):
         dets.append(eng.forward(img))
         eng.close()
     assert np.array_equal(dets[0], dets[1])
+
+
+def test_fused_1x1_tail_equals_separate_launch(hiplib):
+    """A 1x1 conv folded into the epilogue of the 3x3 conv that feeds it (tile plan code cfg + 10000) gives the same
+    bits as the two separate launches, on every producer the planner marks as fusable (with and without a shortcut)."""
+    size = 160
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=5)
+    img = np.random.default_rng(9).integers(0, 256, (2, size, size, 3), dtype=np.uint8)
+    ref = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16, keep_layers=True)
+    ref.set_weights(flat); want = ref.forward(img); ref.close()
+    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16)
+    eng.set_weights(flat)
+    cfgs = np.full(eng.num_layers, -1, np.int32)
+    fused = 0
+    for i, s in enumerate(secs[1:]):
+        if s["type"] != "convolutional" or int(s["filters"]) not in (128, 256):
+            continue
+        trial = cfgs.copy(); trial[i] = (32 if int(s["filters"]) == 256 else 16) + 10000
+        try:
+            eng.set_tile_configs(trial)
+            cfgs = trial; fused += 1
+        except hiplib.YoloError:
+            pass                                            # not followed by a foldable 1x1 conv
+    assert fused >= 10                                      # 2 at 104x104, 8 + 2 at 52x52
+    eng.set_tile_configs(cfgs)
+    assert np.array_equal(eng.get_tile_configs()[cfgs >= 0], cfgs[cfgs >= 0])
+    got = eng.forward(img)
+    assert np.array_equal(got, want)
+    # and through the graph path, twice (capture + replay)
+    import torch
+    dimg = torch.from_numpy(img).cuda(); boxes = torch.zeros((2, 20 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        eng.detect_graph(dimg, boxes, counts, score_thr=0.3, iou_thr=0.5, max_out=20)
+    eng.synchronize()
+    eng.close()

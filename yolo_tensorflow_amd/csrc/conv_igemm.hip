@@ -97,7 +97,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_loader = NL == 0 || wave_id >= NC;          // wave-uniform role
-    const bool is_consumer = NL == 0 || wave_id < NC;
+    // deliberately a run-time value even when NL == 0 (always true then): with the branch folded away the scheduler
+    // overlaps more of the K-step and the 176x128 shape goes from 240 to 272 VGPRs, i.e. from two resident workgroups
+    // per CU to one
+    const bool is_consumer = wave_id < NC;
     const int wid = NL > 0 ? (wave_id >= NC ? wave_id - NC : 0) : wave_id;   // index among the loading waves
     const int wpi = wave_id % WP, wci = (wave_id / WP) % WC;
 
@@ -222,6 +225,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = a.Kpad / BKE;
+    // fused 1x1 tail (see the epilogue): one channel tile covers the whole output (BC == Cout, checked by the host), the
+    // consumer waves split the C2 = BC / 2 tail channels 16 apiece
+    // (8-wave shapes only: in the 4-wave 176x128 shapes the extra live registers push the kernel past 256 VGPRs and cost the
+    // second resident workgroup per CU -- measured slower overall even where the pair itself got faster)
+    constexpr bool TAIL_OK = EB == 2 && !DIAG && WP == 1 && NC == 8 && NC * 16 == BC / 2;
     // SPREAD: place one LDS-DMA of the next stage behind every MFMA group instead of issuing the whole stage first
     // (possible when the loads sit in the MFMAs' basic block: every wave loads, scalar tap cursor).  Measured A/B on one
     // MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms) and fp8 (2.39 vs 2.34 ms) -- a DMA
@@ -402,6 +410,14 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 }
             }
         }
+        // fused 1x1 tail: its filter fragments (16 rows x BC per consumer wave) are fetched here when the registers allow
+        // (8-wave shapes), so their latency hides behind the epilogue; the 4-wave shapes fetch them just before use
+        constexpr bool TAIL_EARLY = TAIL_OK && NL == 0;       // the 12-wave role-split shape has no registers to spare
+        bf16x8 fw2[TAIL_OK ? BC / 32 : 1];
+        if (TAIL_EARLY) if (a.w2 && is_consumer)
+#pragma unroll
+            for (int kk = 0; kk < BC / 32; ++kk)
+                fw2[kk] = *(const bf16x8 *)((const bf16_t *)a.w2 + (size_t)(wave_id * 16 + l15) * a.K2pad + (kk * 4 + lq) * 8);
         block_barrier();                                      // every wave is done reading the last stage
         if (is_consumer)
 #pragma unroll
@@ -482,8 +498,68 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
                     }
                     o = uint4{ov[0], ov[1], ov[2], ov[3]};
+                    if (TAIL_OK && a.w2) *(uint4 *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                 }
                 *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
+            }
+            if (TAIL_OK) if (a.w2) {
+                // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.
+                //      Consumer wave w owns output channels 16w..16w+15 for every pixel of the tile; its filter fragments
+                //      (16 rows x BC, 8 KB) come straight from global; K is walked in ascending 32-wide steps, the order of
+                //      the stand-alone 1x1 kernel, so the result is bit-identical to the unfused layer. ----
+                constexpr int C2 = BC / 2, K2S = BC / 32, RS2 = C2 * 2 + 16;
+                char *const st2 = smem + BP * RS;
+                if (!TAIL_EARLY && is_consumer)
+#pragma unroll
+                    for (int kk = 0; kk < K2S; ++kk)
+                        fw2[kk] = *(const bf16x8 *)((const bf16_t *)a.w2 + (size_t)(wave_id * 16 + l15) * a.K2pad + (kk * 4 + lq) * 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                block_barrier();                                   // tile (with the shortcut added) complete in LDS
+                if (is_consumer) {
+                    const float4 b2v = *(const float4 *)(a.b2 + wave_id * 16 + lq * 4);
+                    auto finish = [&](const f32x4 &acc2, int j) {
+                        float v[4] = {acc2[0] + b2v.x, acc2[1] + b2v.y, acc2[2] + b2v.z, acc2[3] + b2v.w};
+                        if (a.act2 == ACT_LEAKY) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
+                        }
+                        uint2 pk;
+                        pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
+                        pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
+                        *(uint2 *)(st2 + (j * 16 + l15) * RS2 + (wave_id * 16 + lq * 4) * 2) = pk;
+                    };
+                    // two pixel tiles at a time: two independent accumulation chains keep the matrix pipe fed (each chain
+                    // is K-ordered); the loop stays rolled so the fragment reads are not all hoisted (176 VGPRs otherwise)
+#pragma unroll 1
+                    for (int j = 0; j + 1 < TP; j += 2) {
+                        f32x4 acc2a = {0.f, 0.f, 0.f, 0.f}, acc2b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < K2S; ++kk) {
+                            const bf16x8 xa = *(const bf16x8 *)(smem + (j * 16 + l15) * RS + (kk * 4 + lq) * 16);
+                            const bf16x8 xb = *(const bf16x8 *)(smem + ((j + 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
+                            acc2a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], xa, acc2a, 0, 0, 0);
+                            acc2b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], xb, acc2b, 0, 0, 0);
+                        }
+                        finish(acc2a, j); finish(acc2b, j + 1);
+                    }
+                    if (TP & 1) {
+                        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < K2S; ++kk) {
+                            const bf16x8 x = *(const bf16x8 *)(smem + ((TP - 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], x, acc2, 0, 0, 0);
+                        }
+                        finish(acc2, TP - 1);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                block_barrier();
+                constexpr int CPR2 = C2 / 8;
+                for (int c = tid; c < BP * CPR2; c += NT) {
+                    const int row = c / CPR2, cc = c - row * CPR2;
+                    const int m = pt * BP + row;
+                    if (m < M) *(uint4 *)((bf16_t *)a.out2 + (size_t)m * a.out2_stride + cc * 8) = *(const uint4 *)(st2 + row * RS2 + cc * 16);
+                }
             }
         }
     } else if (is_consumer) {
@@ -532,7 +608,8 @@ constexpr size_t conv_lds_bytes()
     constexpr int RG = 64 / (BK * 2 / 16);
     constexpr int LA = ((BP + RG - 1) / RG + NW - 1) / NW, LB = ((BC + RG - 1) / RG + NW - 1) / NW;
     constexpr size_t stage = (size_t)(LA + LB) * NW * RG * (BK * 2);
-    constexpr size_t lds0 = (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16);
+    constexpr bool tail = WP == 1 && WC == 8 && WC * 16 == BC / 2; // TAIL_OK shapes also stage the tail's [BP][BC/2] tile
+    constexpr size_t lds0 = (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16) + (tail ? (size_t)BP * (BC + 16) : 0);
     return lds0 > ldso ? lds0 : ldso;
 }
 
@@ -681,6 +758,13 @@ struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl; };
 static const CfgDesc kCfgs[] = {CONV_CFGS(X)};
 #undef X
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
+bool conv_cfg_tail_ok(int cfg, int cout)
+{
+    if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
+    const CfgDesc &c = kCfgs[cfg];
+    const int bc = c.wc * c.tc * 16;
+    return c.wp == 1 && c.wc == 8 && c.wc * 16 == bc / 2 && bc == cout;
+}
 const char *conv_cfg_name(int cfg)
 {
     static char names[64][32];

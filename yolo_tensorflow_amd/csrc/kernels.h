@@ -34,6 +34,10 @@ struct ConvArgs {
     const float *oscale;                 // [Cout_pad] or nullptr (== 1)
     float out_inv_scale, res_scale;
     float mid_scale, mid_inv_scale;      // fused shortcut: this conv's own output scale (quantised before the add)
+    // fused 1x1 tail (bf16, tile configurations with conv_cfg_tail_ok): out2[pixel][C2] = act2(W2 . out[pixel][:] + b2),
+    // computed from the finished output tile while it is still in LDS (the 1x1 conv that follows a 3x3 in every darknet
+    // residual block).  w2 == nullptr: none.  C2 = Cout / 2, W2 packed [C2 pad][K2pad], k = channel of `out`.
+    const void *w2; const float *b2; void *out2; int out2_stride, K2pad, act2;
     int N, H, W, Cin_pad;
     int Ho, Wo, Cout;
     int ksize, stride, pad;
@@ -66,6 +70,7 @@ const char *conv_cfg_name(int cfg);
 // rough preference used when no autotune ran
 int conv_pick_cfg(const ConvArgs &a);
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
+bool conv_cfg_tail_ok(int cfg, int cout);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);

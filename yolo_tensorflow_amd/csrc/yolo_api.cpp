@@ -42,6 +42,9 @@ struct Layer {
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
+    // fused 1x1 tail of the tiled conv kernel: `tail_layer` (on the producer) = index of the 1x1 conv that can be computed
+    // in the producer's epilogue, `fused_into` (on that 1x1) = the producer; `tail_on` = the plan uses it
+    int tail_layer = -1, fused_into = -1; bool tail_on = false;
     // shortcut/route bookkeeping
     bool noop = false;                   // output is an alias / was produced by someone else
     std::vector<int> copy_inputs;        // route inputs that must be copied (could not be placed)
@@ -280,6 +283,21 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             }
         }
     }
+    // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
+    // fused shortcut) read by a 1x1/s1 conv with half as many filters
+    if (c->dtype == YOLO_BF16 && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
+        for (int i = 0; i + 1 < NL; ++i) {
+            Layer &P = c->layers[i];
+            if (P.type != L_CONV || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
+            int o = i;
+            if (P.residual_from >= -1) o = i + 1;            // its shortcut was folded into it: consumers read layer i+1
+            const int j = o + 1;
+            if (j >= NL) continue;
+            Layer &T = c->layers[j];
+            if (T.type == L_CONV && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
+                T.residual_from < -1 && !T.stem_tail) { P.tail_layer = j; T.fused_into = i; }
+        }
+    }
     // storage assignment: st_of[i] = storage holding layer i's output
     std::vector<int> place_route(NL, -1), place_off(NL, 0);
     for (int i = 0; i < NL; ++i) {
@@ -332,7 +350,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.storage < 0) continue;
-        if (!L.noop) { Storage &s = c->storages[L.storage]; s.def = std::min(s.def, i); s.last = std::max(s.last, i); }
+        if (!L.noop) { Storage &s = c->storages[L.storage]; s.def = std::min(s.def, L.fused_into >= 0 ? L.fused_into : i); s.last = std::max(s.last, i); }
         for (int j : L.in) if (j >= 0 && c->layers[j].storage >= 0) { Storage &s = c->storages[c->layers[j].storage]; s.last = std::max(s.last, i); }
         if (L.type == L_CONV && L.residual_from >= 0) { Storage &s = c->storages[c->layers[L.residual_from].storage]; s.last = std::max(s.last, i); }
     }
@@ -408,6 +426,10 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
+    if (L.tail_on && L.tail_layer >= 0) {
+        const Layer &T = c->layers[L.tail_layer];
+        a.w2 = T.d_w; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
+    }
     if (L.out.dt == DT_FP8) {
         if (L.residual_from >= -1) {     // fused shortcut: this conv writes layer li+1's tensor
             a.mid_scale = c->user_scale[li]; a.mid_inv_scale = 1.f / c->user_scale[li];
@@ -428,6 +450,7 @@ int run_layer(yolo_ctx *c, int i, int n)
     switch (L.type) {
     case L_CONV: {
         if (L.stem_skip || L.stem_tail) break;
+        if (L.fused_into >= 0 && c->layers[L.fused_into].tail_on) break;        // computed in the producer's epilogue
         if (L.stem) {
             const Layer &A = c->layers[0];
             StemArgs t; memset(&t, 0, sizeof t);
@@ -450,6 +473,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
         break; }
@@ -937,6 +961,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
+    for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
     for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
@@ -978,6 +1003,49 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         if (it != score.end()) for (auto &kv : it->second) if (kv.second < bt) { bt = kv.second; best = kv.first; }
         L.tile_cfg = best;
     }
+    // second pass: fold 1x1 convs into their producers where that beats the best unfused pair.  Base = the plan just
+    // chosen; candidate = every tail-capable tile shape on all producers at once; decided per producer shape.
+    {
+        int r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
+        std::vector<float> base(ms);
+        std::vector<int> base_cfg(NL, -1);
+        for (int i = 0; i < NL; ++i) base_cfg[i] = c->layers[i].tile_cfg;
+        std::map<std::string, std::pair<double, int>> best;         // producer shape -> (pair time, cfg), cfg -1 = unfused
+        for (int i = 0; i < NL; ++i) {
+            const Layer &L = c->layers[i];
+            if (L.type != L_CONV || L.tail_layer < 0) continue;
+            auto &b = best[shape_key(L)];
+            if (b.second == 0 && b.first == 0) b = {0.0, -1};
+            b.first += base[i] + base[L.tail_layer];
+        }
+        for (int cfg = 0; cfg < conv_num_cfgs(); ++cfg) {
+            bool any = false;
+            for (int i = 0; i < NL; ++i) {
+                Layer &L = c->layers[i];
+                if (L.type != L_CONV || L.tail_layer < 0) continue;
+                const bool ok = conv_cfg_tail_ok(cfg, L.filters);
+                L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
+            }
+            if (!any) continue;
+            r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
+            std::map<std::string, double> t;
+            for (int i = 0; i < NL; ++i) {
+                const Layer &L = c->layers[i];
+                if (L.type == L_CONV && L.tail_layer >= 0 && L.tail_on) t[shape_key(L)] += ms[i] + ms[L.tail_layer];
+            }
+            for (auto &kv : t) {
+                auto &b = best[kv.first];
+                if (getenv("YOLO_TUNE_VERBOSE")) fprintf(stderr, "tune-tail %s cfg %d %-16s fused pair %.4f ms (unfused best so far %.4f)\n", kv.first.c_str(), cfg, conv_cfg_name(cfg), kv.second, b.first);
+                if (kv.second < b.first) b = {kv.second, cfg};
+            }
+        }
+        for (int i = 0; i < NL; ++i) {
+            Layer &L = c->layers[i];
+            if (L.type != L_CONV || L.tail_layer < 0) continue;
+            const auto &b = best[shape_key(L)];
+            L.tail_on = b.second >= 0; L.tile_cfg = b.second >= 0 ? b.second : base_cfg[i];
+        }
+    }
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0;
     return YOLO_OK;
 }
@@ -985,7 +1053,11 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
 int yolo_get_tile_configs(const yolo_ctx *c, int32_t *cfgs)
 {
     if (!c || !cfgs) return YOLO_ERR_INVALID;
-    for (size_t i = 0; i < c->layers.size(); ++i) cfgs[i] = c->layers[i].type == L_CONV ? c->layers[i].tile_cfg : -1;
+    // a conv whose plan folds the following 1x1 conv into its epilogue is reported as cfg + 10000
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        const Layer &L = c->layers[i];
+        cfgs[i] = L.type == L_CONV ? (L.tail_on && L.tile_cfg >= 0 ? L.tile_cfg + 10000 : L.tile_cfg) : -1;
+    }
     return YOLO_OK;
 }
 
@@ -994,10 +1066,14 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
     if (!c || !cfgs) return YOLO_ERR_INVALID;
     for (size_t i = 0; i < c->layers.size(); ++i) {
         if (c->layers[i].type != L_CONV) continue;
-        const int v = cfgs[i];
+        int v = cfgs[i]; bool tail = false;
+        if (v >= 10000) { v -= 10000; tail = true; }
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
-        c->layers[i].tile_cfg = v;
+        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters)))
+            return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
+        c->layers[i].tile_cfg = v; c->layers[i].tail_on = tail;
     }
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0;
     return YOLO_OK;
 }
 
