@@ -103,6 +103,14 @@ const char *yolo_last_error(const yolo_ctx *ctx);
  * reference loaders' fixed counts V3/yolo_v3.py:278 / D2T V2 :351, 0 = auto), folds BN
  * (W*g/sqrt(v+1e-5), b - m*g/sqrt(v+1e-5), fp32), packs and uploads. */
 int yolo_load_darknet_weights(yolo_ctx *ctx, const char *path, int header_ints);
+/* Export artifact: ONE self-describing file holding the cfg text, the run configuration (dtype, semantics,
+ * decode), the folded + packed device-ready parameters of every conv (fp8: codes and scales) and the tile plan.  It is
+ * to this library what the frozen `.pb` (input -> detected_boxes / detected_scores / detected_classes,
+ * D2T/YOLO_V3_convert_darkenet_to_Tensorflow.py:99-104, D2T/object_detect.py:64-99) is to the reference: a caller
+ * needs nothing else to run detections.  The file is checksummed; a mismatch, truncation or a packing that does not
+ * fit the topology is an error, never a partial load. */
+int yolo_export(yolo_ctx *ctx, const char *path);
+yolo_ctx *yolo_create_from_file(const char *path, int max_batch, int device, void *stream, int keep_layers, char *err, size_t err_len);
 /* Same from the float stream that follows the header (n floats, must match the topology). */
 int yolo_set_weights(yolo_ctx *ctx, const float *flat, size_t n);
 size_t yolo_weights_count(const yolo_ctx *ctx);

@@ -129,3 +129,36 @@ def test_yolo_v2_entry_points(hiplib):
     assert len(ws) > 0
     assert np.array_equal(b, wb) and np.array_equal(s, ws) and np.array_equal(k, wk)
     m.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp32", "fp8"])
+def test_export_artifact_round_trip(hiplib, tmp_path, dtype_name):
+    """yolo_export -> yolo_create_from_file: the artifact alone (no cfg, no .weights) reproduces the detections bit for
+    bit; truncation, corruption and foreign files are rejected with an error (never a partial load)."""
+    dtype = {"bf16": hiplib.BF16, "fp32": hiplib.FP32, "fp8": hiplib.FP8}[dtype_name]
+    size = 96
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 11)
+    img = np.random.default_rng(12).integers(0, 256, (2, size, size, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2, dtype=dtype, semantics=hiplib.SEM_DARKNET, decode=hiplib.DECODE_PIXEL)
+    if dtype == hiplib.FP8:
+        sc = np.ones(eng.num_layers, np.float32); sc[::3] = 0.5; sc[1::3] = 0.25
+        eng.set_act_scales(sc)
+    with pytest.raises(hiplib.YoloError):
+        eng.export(str(tmp_path / "early.yolohip"))            # nothing to export before weights are loaded
+    eng.set_weights(flat)
+    want = eng.forward(img)
+    path = str(tmp_path / "net.yolohip")
+    eng.export(path); eng.close()
+    eng2 = hiplib.Engine.from_file(path, max_batch=2)
+    assert (eng2.size, eng2.rows, eng2.attrs) == (size, want.shape[1], 85)
+    assert np.array_equal(eng2.forward(img), want)              # same semantics / decode mode / scales / parameters
+    eng2.close()
+    blob = open(path, "rb").read()
+    bad = str(tmp_path / "bad.yolohip")
+    for mutate in (lambda b: b[:len(b) // 2], lambda b: b[:-1], lambda b: b[:4096] + bytes([b[4096] ^ 1]) + b[4097:], lambda b: b"NOTYOLO1" + b[8:], lambda b: b""):
+        open(bad, "wb").write(mutate(blob))
+        with pytest.raises(hiplib.YoloError):
+            hiplib.Engine.from_file(bad)
+    with pytest.raises(hiplib.YoloError):
+        hiplib.Engine.from_file(str(tmp_path / "missing.yolohip"))

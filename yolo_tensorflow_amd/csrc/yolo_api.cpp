@@ -64,7 +64,7 @@ struct Storage { int def = 1 << 30, last = -1; size_t bytes = 0; int phys = -1; 
 }  // namespace
 
 struct yolo_ctx {
-    std::string err;
+    std::string err, cfg_text;
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     int max_batch = 1, dtype = YOLO_BF16, semantics = YOLO_SEM_TF, decode = YOLO_DECODE_RATIO, keep_layers = 0;
@@ -666,6 +666,7 @@ yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
     else { if (hipStreamCreate(&c->stream) != hipSuccess) return bail(c, "yolo_create: hipStreamCreate failed"); c->own_stream = true; }
     std::vector<Section> secs; std::string perr;
+    c->cfg_text = cfg->cfg_text ? cfg->cfg_text : "";
     if (!parse_cfg(cfg->cfg_text, secs, perr)) return bail(c, perr);
     if (build_plan(c, secs) != YOLO_OK) return bail(c, c->err);
     if (allocate(c) != YOLO_OK) return bail(c, c->err);
@@ -747,6 +748,99 @@ int yolo_load_darknet_weights(yolo_ctx *c, const char *path, int header_ints)
     size_t got = fread(flat.data(), 4, n, f); fclose(f);
     if (got != n) return fail(c, YOLO_ERR_IO, "short read on '%s'", path);
     return yolo_set_weights(c, flat.data(), n);
+}
+
+// ---- export artifact: one self-describing file = cfg text + run configuration + the folded, packed,
+//      device-ready parameters of every conv (+ fp8 scales, + the tile plan).  Counterpart of the reference's frozen
+//      `.pb` (D2T/YOLO_V3_convert_darkenet_to_Tensorflow.py:99-104, D2T/object_detect.py:64-99): `input` in,
+//      boxes / scores / classes out, nothing else needed to run. ----
+namespace {
+struct ArtHeader { char magic[8]; uint32_t version, dtype, semantics, decode, n_layers, num_cfgs, cfg_len, reserved; };
+const char kArtMagic[8] = {'Y', 'O', 'L', 'O', 'H', 'I', 'P', '1'};
+uint64_t fnv1a(uint64_t h, const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+struct ArtWriter {
+    FILE *f; uint64_t h = 1469598103934665603ull; bool ok = true;
+    void put(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; h = fnv1a(h, p, n); }
+};
+struct ArtReader {
+    FILE *f; uint64_t h = 1469598103934665603ull; bool ok = true;
+    void get(void *p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; if (ok) h = fnv1a(h, p, n); }
+};
+}  // namespace
+
+int yolo_export(yolo_ctx *c, const char *path)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_export before weights were loaded");
+    HIPCK(c, hipSetDevice(c->device)); HIPCK(c, hipStreamSynchronize(c->stream));
+    FILE *f = path ? fopen(path, "wb") : nullptr;
+    if (!f) return fail(c, YOLO_ERR_IO, "cannot create '%s'", path ? path : "(null)");
+    ArtWriter w{f};
+    const uint32_t NL = (uint32_t)c->layers.size();
+    ArtHeader hd; memset(&hd, 0, sizeof hd); memcpy(hd.magic, kArtMagic, 8);
+    hd.version = 1; hd.dtype = c->dtype; hd.semantics = c->semantics; hd.decode = c->decode; hd.n_layers = NL;
+    hd.num_cfgs = (uint32_t)conv_num_cfgs(); hd.cfg_len = (uint32_t)c->cfg_text.size();
+    w.put(&hd, sizeof hd); w.put(c->cfg_text.data(), c->cfg_text.size());
+    std::vector<float> sc(c->user_scale); sc.resize(NL, 1.f); w.put(sc.data(), NL * 4);
+    std::vector<int32_t> plan(NL); yolo_get_tile_configs(c, plan.data()); w.put(plan.data(), NL * 4);
+    std::vector<uint8_t> buf;
+    for (auto &L : c->layers) {
+        if (L.type != L_CONV) continue;
+        const uint64_t sz[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        w.put(sz, sizeof sz);
+        const void *src[3] = {L.d_w, L.d_b, L.d_sc}; const size_t bytes[3] = {(size_t)sz[0], (size_t)sz[1] * 4, (size_t)sz[2] * 4};
+        for (int k = 0; k < 3; ++k) {
+            if (!bytes[k]) continue;
+            buf.resize(bytes[k]);
+            if (hipMemcpy(buf.data(), src[k], bytes[k], hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(c, YOLO_ERR_HIP, "export: device read failed"); }
+            w.put(buf.data(), bytes[k]);
+        }
+    }
+    const uint64_t sum = w.h;
+    if (w.ok && fwrite(&sum, 1, 8, f) != 8) w.ok = false;
+    if (fclose(f) != 0) w.ok = false;
+    return w.ok ? YOLO_OK : fail(c, YOLO_ERR_IO, "short write on '%s'", path);
+}
+
+yolo_ctx *yolo_create_from_file(const char *path, int max_batch, int device, void *stream, int keep_layers, char *err, size_t err_len)
+{
+    auto bail = [&](yolo_ctx *c, const std::string &m) -> yolo_ctx * { if (err && err_len) snprintf(err, err_len, "%s", m.c_str()); if (c) yolo_destroy(c); return nullptr; };
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return bail(nullptr, std::string("cannot open '") + (path ? path : "(null)") + "'");
+    ArtReader r{f};
+    ArtHeader hd; r.get(&hd, sizeof hd);
+    if (!r.ok || memcmp(hd.magic, kArtMagic, 8) != 0 || hd.version != 1 || hd.cfg_len > (1u << 24) || hd.n_layers > 4096) { fclose(f); return bail(nullptr, "not a YOLOHIP1 artifact (or an unsupported version)"); }
+    std::string cfg_text(hd.cfg_len, '\0'); r.get(&cfg_text[0], hd.cfg_len);
+    std::vector<float> sc(hd.n_layers); r.get(sc.data(), (size_t)hd.n_layers * 4);
+    std::vector<int32_t> plan(hd.n_layers); r.get(plan.data(), (size_t)hd.n_layers * 4);
+    if (!r.ok) { fclose(f); return bail(nullptr, "truncated artifact"); }
+    yolo_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg; cfg.cfg_text = cfg_text.c_str(); cfg.max_batch = max_batch; cfg.dtype = (int)hd.dtype; cfg.semantics = (int)hd.semantics;
+    cfg.decode = (int)hd.decode; cfg.device = device; cfg.keep_layers = keep_layers; cfg.stream = stream;
+    yolo_ctx *c = yolo_create(&cfg, err, err_len);
+    if (!c) { fclose(f); return nullptr; }
+    if (c->layers.size() != hd.n_layers) { fclose(f); return bail(c, "artifact layer count does not match its own cfg"); }
+    if (c->dtype == YOLO_FP8 && yolo_set_act_scales(c, sc.data(), (int)hd.n_layers) != YOLO_OK) { fclose(f); return bail(c, c->err); }
+    std::vector<uint8_t> buf;
+    for (auto &L : c->layers) {
+        if (L.type != L_CONV) continue;
+        uint64_t sz[3]; r.get(sz, sizeof sz);
+        const uint64_t want[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        if (!r.ok || sz[0] != want[0] || sz[1] != want[1] || sz[2] != want[2]) { fclose(f); return bail(c, "artifact parameters do not fit the topology (truncated file or different packing)"); }
+        void *dst[3] = {L.d_w, L.d_b, L.d_sc}; const size_t bytes[3] = {(size_t)sz[0], (size_t)sz[1] * 4, (size_t)sz[2] * 4};
+        for (int k = 0; k < 3; ++k) {
+            if (!bytes[k]) continue;
+            buf.resize(bytes[k]); r.get(buf.data(), bytes[k]);
+            if (!r.ok) { fclose(f); return bail(c, "truncated artifact"); }
+            if (hipMemcpy(dst[k], buf.data(), bytes[k], hipMemcpyHostToDevice) != hipSuccess) { fclose(f); return bail(c, "artifact upload failed"); }
+        }
+    }
+    uint64_t sum = 0; const bool got = fread(&sum, 1, 8, f) == 8; fclose(f);
+    if (!got || sum != r.h) return bail(c, "artifact checksum mismatch");
+    c->weights_loaded = true;
+    // the tile plan is only meaningful for the tile table it was tuned with and for a plan that fuses nothing it cannot
+    if (hd.num_cfgs == (uint32_t)conv_num_cfgs() && !keep_layers) { if (yolo_set_tile_configs(c, plan.data()) != YOLO_OK) { std::vector<int32_t> none(hd.n_layers, -1); yolo_set_tile_configs(c, none.data()); } }
+    return c;
 }
 
 int yolo_input_size(const yolo_ctx *c, int *h, int *w, int *ch) { if (!c) return YOLO_ERR_INVALID; if (h) *h = c->in_h; if (w) *w = c->in_w; if (ch) *ch = c->in_c; return YOLO_OK; }

@@ -24,7 +24,7 @@ BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4")
 
 EXPORTS = [
     "yolo_create", "yolo_destroy", "yolo_last_error", "yolo_load_darknet_weights", "yolo_set_weights",
-    "yolo_weights_count", "yolo_set_act_scales", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
+    "yolo_weights_count", "yolo_set_act_scales", "yolo_export", "yolo_create_from_file", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
@@ -63,6 +63,8 @@ def load_library():
     l.yolo_set_weights.argtypes = [P, FP, C.c_size_t]
     l.yolo_weights_count.argtypes = [P]; l.yolo_weights_count.restype = C.c_size_t
     l.yolo_set_act_scales.argtypes = [P, P, I]
+    l.yolo_export.argtypes = [P, C.c_char_p]
+    l.yolo_create_from_file.argtypes = [C.c_char_p, I, I, P, I, C.c_char_p, C.c_size_t]; l.yolo_create_from_file.restype = P
     l.yolo_input_size.argtypes = [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]
     for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_synchronize"):
         getattr(l, n).argtypes = [P]
@@ -136,6 +138,26 @@ class Engine:
         self.num_layers = self.lib.yolo_num_layers(self.ctx)
         self.max_batch = max_batch
         self.dtype = dtype
+
+    @classmethod
+    def from_file(cls, path, max_batch=1, device=0, keep_layers=False, stream=None):
+        """Load an export artifact written by `export` (cfg + run configuration + packed parameters + tile plan)."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        err = C.create_string_buffer(512)
+        self.ctx = self.lib.yolo_create_from_file(os.fsencode(path), max_batch, device, C.c_void_p(stream) if stream else None,
+                                                  1 if keep_layers else 0, err, 512)
+        if not self.ctx:
+            raise YoloError("yolo_create_from_file: " + err.value.decode())
+        h, w, ch = C.c_int(), C.c_int(), C.c_int()
+        self.lib.yolo_input_size(self.ctx, C.byref(h), C.byref(w), C.byref(ch))
+        self.size = h.value
+        self.rows = self.lib.yolo_num_rows(self.ctx); self.attrs = self.lib.yolo_num_attrs(self.ctx)
+        self.num_layers = self.lib.yolo_num_layers(self.ctx); self.max_batch = max_batch; self.dtype = None
+        return self
+
+    def export(self, path):
+        self._check(self.lib.yolo_export(self.ctx, os.fsencode(path)), "yolo_export")
 
     def _check(self, rc, what):
         if rc != 0:
