@@ -56,7 +56,8 @@ enum yolo_decode { YOLO_DECODE_RATIO = 0, YOLO_DECODE_PIXEL = 1 };
 enum yolo_location { YOLO_HOST = 0, YOLO_DEVICE = 1 };
 enum yolo_image_format {
     YOLO_IMG_U8 = 0,           /* uint8  [n,S,S,3] already at network size */
-    YOLO_IMG_F32 = 1           /* float32 [n,S,S,3] already at network size */
+    YOLO_IMG_F32 = 1,          /* float32 [n,S,S,3] already at network size */
+    YOLO_IMG_F32_CHW = 2       /* float32 [n,3,S,S] planar: darknet's `image` layout (DN/image.c get_pixel) */
 };
 enum yolo_nms_mode {
     YOLO_NMS_TF = 0,           /* tf.image.non_max_suppression: class-agnostic, `>` iou, top max_out (row N1) */
@@ -141,6 +142,11 @@ int yolo_forward(yolo_ctx *ctx, const void *images, int n, int fmt, int loc, flo
  * S x S on the device (D2T/YOLO_V3_convert...py:106-111), then as yolo_forward with n = 1. */
 int yolo_forward_image_u8(yolo_ctx *ctx, const uint8_t *image, int h, int w, int loc,
                           float *detections_out, int out_loc);
+/* darknet's network_predict_image (DN/network.c:579-586): ONE planar float image [3,h,w] (0..1) of any size ->
+ * letterbox_image (DN/image.c:960-981: aspect-preserving resize_image DN/image.c:1347-1393, 0.5 fill, centred) on the
+ * device, then as yolo_forward with n = 1. */
+int yolo_forward_letterbox_chw(yolo_ctx *ctx, const float *image_chw, int w, int h, int loc,
+                               float *detections_out, int out_loc);
 
 /* Threshold + NMS on the resident decoded tensor of the last forward (rows S, N1/N3).
  * boxes_out: [n * max_out] caller-owned, counts_out: [n]; both at out_loc.
@@ -200,6 +206,12 @@ int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const fl
                    int img_size, int decode, int region, float *out, int device);
 /* threshold + NMS over det [n,rows,attrs] fp32.  nms_mode bits 8..19 / 20..31 carry image height / width for
  * YOLO_NMS_PER_CLASS (V2 pixel boxes); select_mode bit 8 set = rows already hold corners (x0,y0,x1,y1). */
+/* darknet's do_nms_sort (by_objectness = 0) / do_nms_obj (1), DN/box.c:21-89, on caller arrays (host): boxes [n] (cx,cy,w,h),
+ * prob [n][classes], objectness [n]; suppressed entries are zeroed IN PLACE (prob[j][k], or objectness[j] and all of
+ * prob[j]); detections whose objectness is 0 do not take part.  n <= 4096.  Array order is left unchanged (the
+ * reference qsorts its array; callers only read the surviving probabilities). */
+int yolo_op_nms_detections(const float *boxes_xywh, float *prob, float *objectness, int n, int classes, float thresh,
+                           int by_objectness, int device);
 int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr,
                         int max_out, int nms_mode, int select_mode, yolo_box *boxes_out,
                         int32_t *counts_out, int device);

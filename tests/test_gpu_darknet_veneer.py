@@ -1,0 +1,144 @@
+"""libdarknet_hip.so (include/darknet_hip.h) against the reference's own libdarknet, compiled CPU-only from its sources
+(oracle/_ref, oracle/Makefile): the same cfg, .weights file and image go through `load_network` ->
+`network_predict_image` (letterbox) -> `get_network_boxes` -> `do_nms_sort` / `do_nms_obj` of BOTH libraries, called
+through the same ctypes declarations the reference's binding uses (D2T/darknet.py:20-115)."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+from oracle import darknet_ref as DR
+from yolo_tensorflow_amd import darknet_io as IO
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class IMAGE(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("c", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+def _bind(lib):
+    lib.load_network.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; lib.load_network.restype = C.c_void_p
+    lib.free_network.argtypes = [C.c_void_p]
+    lib.network_width.argtypes = [C.c_void_p]; lib.network_height.argtypes = [C.c_void_p]
+    lib.network_predict_image.argtypes = [C.c_void_p, IMAGE]; lib.network_predict_image.restype = C.POINTER(C.c_float)
+    lib.network_predict.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; lib.network_predict.restype = C.POINTER(C.c_float)
+    lib.get_network_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    lib.get_network_boxes.restype = C.POINTER(DR.DETECTION)
+    lib.free_detections.argtypes = [C.POINTER(DR.DETECTION), C.c_int]
+    lib.do_nms_sort.argtypes = [C.POINTER(DR.DETECTION), C.c_int, C.c_int, C.c_float]
+    lib.do_nms_obj.argtypes = [C.POINTER(DR.DETECTION), C.c_int, C.c_int, C.c_float]
+    return lib
+
+
+def _collect(dets, n, classes):
+    bb = np.zeros((n, 4), np.float32); obj = np.zeros(n, np.float32); pr = np.zeros((n, classes), np.float32)
+    for i in range(n):
+        d = dets[i]
+        bb[i] = (d.bbox.x, d.bbox.y, d.bbox.w, d.bbox.h); obj[i] = d.objectness
+        pr[i] = np.ctypeslib.as_array(d.prob, shape=(classes,))
+    return bb, obj, pr
+
+
+@pytest.fixture(scope="module")
+def pair(tmp_path_factory, hiplib):
+    if not DR.available():
+        pytest.skip("oracle/_ref/libdarknet_ref.so not built")
+    os.environ["DARKNET_HIP_DTYPE"] = "fp32"
+    tmp = tmp_path_factory.mktemp("veneer")
+    size = 160
+    txt = IO.with_input_size(IO.cfg_text("yolov3-tiny"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 21, obj_bias=0.0)
+    cfg = str(tmp / "net.cfg"); wf = str(tmp / "net.weights")
+    open(cfg, "w").write(txt); IO.write_weights_file(wf, flat, 0, 2)
+    ref = _bind(DR.lib())
+    ven = _bind(C.CDLL(os.path.join(ROOT, "yolo_tensorflow_amd", "libdarknet_hip.so")))
+    with DR._Quiet():
+        rnet = ref.load_network(cfg.encode(), wf.encode(), 0)
+        ref.set_batch_network(rnet, 1)
+    vnet = ven.load_network(cfg.encode(), wf.encode(), 0)
+    assert vnet and ven.network_width(vnet) == size and ven.network_height(vnet) == size
+    yield ref, rnet, ven, vnet, size
+    ven.free_network(vnet)
+    ref.free_network(rnet)
+
+
+def _predict_both(pair, w, h, seed):
+    ref, rnet, ven, vnet, size = pair
+    img = np.ascontiguousarray(np.random.default_rng(seed).random((3, h, w), dtype=np.float32))
+    im = IMAGE(w, h, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+    ref.network_predict_image(rnet, im)
+    out = ven.network_predict_image(vnet, im)
+    assert bool(out)
+    return img
+
+
+@pytest.mark.parametrize("w,h,relative", [(200, 120, 1), (96, 250, 1), (160, 160, 0), (331, 207, 0)])
+def test_predict_image_and_boxes_match_libdarknet(pair, w, h, relative):
+    ref, rnet, ven, vnet, size = pair
+    _predict_both(pair, w, h, seed=w * 7 + h)
+    # a threshold that no objectness sits within 2e-3 of, so both sides select the same boxes
+    n0 = C.c_int(0)
+    d0 = ref.get_network_boxes(rnet, w, h, 0.0, .5, None, relative, C.byref(n0))
+    _, obj_all, _ = _collect(d0, n0.value, 80); ref.free_detections(d0, n0.value)
+    cand = np.sort(obj_all)[::-1]
+    thresh = None
+    for k in range(40, len(cand) - 1):
+        if cand[k] - cand[k + 1] > 8e-3:
+            thresh = float((cand[k] + cand[k + 1]) / 2); break
+    assert thresh is not None
+    nr, nv = C.c_int(0), C.c_int(0)
+    dr = ref.get_network_boxes(rnet, w, h, thresh, .5, None, relative, C.byref(nr))
+    dv = ven.get_network_boxes(vnet, w, h, thresh, .5, None, relative, C.byref(nv))
+    assert nv.value == nr.value > 20
+    br, orr, pr = _collect(dr, nr.value, 80); bv, ov, pv = _collect(dv, nv.value, 80)
+    scale = max(w, h) if not relative else 1.0
+    np.testing.assert_allclose(bv, br, rtol=2e-3, atol=2e-3 * scale)       # same order: head, cell, anchor
+    np.testing.assert_allclose(ov, orr, rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(pv, pr, rtol=2e-3, atol=2e-3)               # entries near the threshold may flip to 0
+    # NMS on identical inputs: give the veneer the reference's detections so that both sides start from the same bits
+    for i in range(nr.value):
+        dv[i].bbox = dr[i].bbox; dv[i].objectness = dr[i].objectness
+        C.memmove(dv[i].prob, dr[i].prob, 80 * 4)
+    ref.do_nms_sort(dr, nr.value, 80, 0.45); ven.do_nms_sort(dv, nv.value, 80, 0.45)
+    _, _, pr2 = _collect(dr, nr.value, 80); br2 = _collect(dr, nr.value, 80)[0]
+    bv2, _, pv2 = _collect(dv, nv.value, 80)
+    # the reference qsorts its array: match rows by box before comparing
+    key_r = {tuple(b): i for i, b in enumerate(br2)}
+    order = [key_r[tuple(b)] for b in bv2]
+    assert sorted(order) == list(range(nr.value))
+    assert np.array_equal(pv2, pr2[order])
+    assert (pv2 == 0).sum() > (pv == 0).sum()                              # something was suppressed
+    ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
+
+
+def test_do_nms_obj_matches_libdarknet(pair):
+    ref, rnet, ven, vnet, size = pair
+    w, h = 180, 140
+    _predict_both(pair, w, h, seed=5)
+    nr, nv = C.c_int(0), C.c_int(0)
+    dr = ref.get_network_boxes(rnet, w, h, 0.35, .5, None, 1, C.byref(nr))
+    dv = ven.get_network_boxes(vnet, w, h, 0.0, .5, None, 1, C.byref(nv))
+    assert nv.value >= nr.value > 20
+    for i in range(nr.value):                                              # identical starting bits on both sides
+        dv[i].bbox = dr[i].bbox; dv[i].objectness = dr[i].objectness
+        C.memmove(dv[i].prob, dr[i].prob, 80 * 4)
+    ref.do_nms_obj(dr, nr.value, 80, 0.3); ven.do_nms_obj(dv, nr.value, 80, 0.3)
+    br, orr, pr = _collect(dr, nr.value, 80); bv, ov, pv = _collect(dv, nr.value, 80)
+    key_r = {tuple(b): i for i, b in enumerate(br)}
+    order = [key_r[tuple(b)] for b in bv]
+    assert np.array_equal(ov, orr[order]) and np.array_equal(pv, pr[order])
+    assert (ov == 0).sum() > 0
+    ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
+
+
+def test_network_predict_planar_input(pair):
+    """network_predict on a planar image already at network size == network_predict_image of the same image."""
+    ref, rnet, ven, vnet, size = pair
+    img = np.ascontiguousarray(np.random.default_rng(1).random((3, size, size), dtype=np.float32))
+    rows = 3 * (5 * 5 + 10 * 10)
+    a = np.ctypeslib.as_array(ven.network_predict(vnet, img.ctypes.data_as(C.POINTER(C.c_float))), shape=(rows, 85)).copy()
+    im = IMAGE(size, size, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+    b = np.ctypeslib.as_array(ven.network_predict_image(vnet, im), shape=(rows, 85)).copy()
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)                 # the letterbox of an S x S image is the identity

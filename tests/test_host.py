@@ -92,3 +92,15 @@ def test_create_rejects_bad_config():
     assert lib.yolo_create(None, err, 256) is None and b"yolo_config" in err.value
     conf = hip._Config(ctypes.sizeof(hip._Config), b"[net]\nwidth=32\nheight=32\nchannels=3\n", 0, 0, 0, 0, 0, 0, None)
     assert lib.yolo_create(ctypes.byref(conf), err, 256) is None and b"max_batch" in err.value
+
+
+def test_darknet_veneer_exports_every_declared_symbol():
+    """libdarknet_hip.so loads and exports every function include/darknet_hip.h declares (no GPU call is made)."""
+    import ctypes, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "darknet_hip.h")).read()
+    names = re.findall(r"^\w[\w \*]*?\b(\w+)\(", text, flags=re.M)
+    assert {"load_network", "network_predict_image", "get_network_boxes", "do_nms_sort", "do_nms_obj", "free_detections"} <= set(names)
+    lib = ctypes.CDLL(os.path.join(root, "yolo_tensorflow_amd", "libdarknet_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), n

@@ -85,7 +85,7 @@ static inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)(
 
 // ---- row P: uint8/float image at network size -> 8-channel (3 real + 5 zero) activation ---------
 template <typename T>
-__global__ void k_preprocess(const void *img, int fmt, size_t npix, float scale, T *out, int out_stride)
+__global__ void k_preprocess(const void *img, int fmt, size_t npix, size_t hw, float scale, T *out, int out_stride)
 {
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -93,9 +93,13 @@ __global__ void k_preprocess(const void *img, int fmt, size_t npix, float scale,
     if (fmt == 0) {
         const uint8_t *s = (const uint8_t *)img + p * 3;
         v[0] = (float)s[0] * scale; v[1] = (float)s[1] * scale; v[2] = (float)s[2] * scale;
-    } else {
+    } else if (fmt == 1) {
         const float *s = (const float *)img + p * 3;
         v[0] = s[0] * scale; v[1] = s[1] * scale; v[2] = s[2] * scale;
+    } else {                                   // planar float [n][3][hw]: darknet's `image` layout (DN/image.c get_pixel)
+        const size_t b = p / hw, q = p - b * hw;
+        const float *s = (const float *)img + b * 3 * hw + q;
+        v[0] = s[0] * scale; v[1] = s[hw] * scale; v[2] = s[2 * hw] * scale;
     }
     Elt<T>::store8(out + p * out_stride, v);
 }
@@ -104,7 +108,7 @@ hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scal
                              int out_stride, hipStream_t s)
 {
     size_t npix = (size_t)n * hw;
-    WITH_DT(out_dt, hipLaunchKernelGGL(k_preprocess<T>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, scale, (T *)out, out_stride));
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_preprocess<T>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, (size_t)hw, scale, (T *)out, out_stride));
     return hipGetLastError();
 }
 
@@ -338,5 +342,45 @@ hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, flo
 {
     size_t npix = (size_t)out.n * out.h * out.w;
     WITH_DT(out.dt, hipLaunchKernelGGL(k_from_f32<T>, grid_for(npix * out.c), dim3(256), 0, s, in, (T *)out.ptr, out.stride, npix, out.c, scale));
+    return hipGetLastError();
+}
+
+// ---- darknet letterbox_image (DN/image.c:960-981) fused with the layout change: a planar float image of any size ->
+//      aspect-preserving resize_image (DN/image.c:1347-1393: horizontal pass then vertical pass, scales (in-1)/(out-1),
+//      last column / row copied) embedded at the centre of a 0.5-filled S x S canvas, written as the 8-channel
+//      network input.  Operation order of the two passes is kept: part = (1-dx)*a + dx*b, then (1-dy)*p0 (+ dy*p1). ----
+template <typename T>
+__global__ void k_letterbox_chw(const float *img, int iw, int ih, int S, int new_w, int new_h, int off_x, int off_y, T *out, int out_stride)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= S * S) return;
+    const int oy = p / S, ox = p - oy * S;
+    const int r = oy - off_y, c = ox - off_x;
+    float v[8] = {0.5f, 0.5f, 0.5f, 0, 0, 0, 0, 0};
+    if ((unsigned)r < (unsigned)new_h && (unsigned)c < (unsigned)new_w) {
+        const float w_scale = (float)(iw - 1) / (float)(new_w - 1), h_scale = (float)(ih - 1) / (float)(new_h - 1);
+        const float sy = (float)r * h_scale; const int iy = (int)sy; const float dy = sy - (float)iy;
+        const bool last_c = c == new_w - 1 || iw == 1, last_r = r == new_h - 1 || ih == 1;
+        const float sx = (float)c * w_scale; const int ix = (int)sx; const float dx = sx - (float)ix;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float *pl = img + (size_t)k * iw * ih;
+            auto part = [&](int row) {
+                if (last_c) return pl[(size_t)row * iw + (iw - 1)];
+                return (1 - dx) * pl[(size_t)row * iw + ix] + dx * pl[(size_t)row * iw + ix + 1];
+            };
+            float val = (1 - dy) * part(iy);
+            if (!last_r) val = val + dy * part(iy + 1);
+            v[k] = val;
+        }
+    }
+    Elt<T>::store8(out + (size_t)p * out_stride, v);
+}
+hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *out, int out_dt, int out_stride, hipStream_t s)
+{
+    int new_w, new_h;
+    if (((float)S / iw) < ((float)S / ih)) { new_w = S; new_h = (ih * S) / iw; } else { new_h = S; new_w = (iw * S) / ih; }
+    if (new_w < 1 || new_h < 1) return hipErrorInvalidValue;
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_letterbox_chw<T>, grid_for((size_t)S * S), dim3(256), 0, s, img, iw, ih, S, new_w, new_h, (S - new_w) / 2, (S - new_h) / 2, (T *)out, out_stride));
     return hipGetLastError();
 }

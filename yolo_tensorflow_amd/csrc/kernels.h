@@ -132,4 +132,6 @@ struct PostArgs {
     void *boxes_out; int *counts_out;   // yolo_box [n*max_out], int [n] (device)
 };
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);
+hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *out, int out_dt, int out_stride, hipStream_t s);
+hipError_t launch_nms_dets(const float4 *boxes, float *prob, float *objectness, int n, int classes, float thresh, int by_obj, hipStream_t s);
 hipError_t launch_boxes_to_corners(const float *in, float *out, size_t nrows, int attrs, hipStream_t s);

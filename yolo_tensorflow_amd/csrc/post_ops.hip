@@ -586,3 +586,62 @@ hipError_t launch_boxes_to_corners(const float *in, float *out, size_t nrows, in
     hipLaunchKernelGGL(k_boxes_to_corners, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, nrows, attrs);
     return hipGetLastError();
 }
+
+// ---- darknet do_nms_sort / do_nms_obj (DN/box.c:21-89) on caller-shaped arrays: boxes [n] (cx,cy,w,h), prob [n][classes],
+//      objectness [n]; suppressed entries are zeroed in place.  One workgroup per class (sort) or one in all (obj):
+//      bitonic sort of (score, index) keys in LDS (descending; ties: lower index first -- qsort leaves tie order
+//      unspecified), then the reference's greedy pass with the inner loop spread over the threads.  Detections with
+//      objectness == 0 do not take part (the reference moves them behind `total`). ----
+#define NMSD_MAX 4096
+__global__ __launch_bounds__(1024) void k_nms_dets(const float4 *boxes, float *prob, float *objectness, int n, int classes, float thresh, int by_obj)
+{
+    __shared__ unsigned long long key[NMSD_MAX];
+    __shared__ unsigned char dead[NMSD_MAX];
+    const int k = by_obj ? -1 : (int)blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int j = tid; j < np2; j += nt) {
+        float sc = 0.f;
+        if (j < n && objectness[j] != 0.f) sc = by_obj ? objectness[j] : prob[(size_t)j * classes + k];
+        // descending order == ascending order of the complemented key; zero / padded entries sort last
+        const unsigned bits = sc > 0.f ? __float_as_uint(sc) : 0u;
+        key[j] = ((unsigned long long)(~bits) << 32) | (unsigned)j;
+        dead[j] = !(j < n && objectness[j] != 0.f);
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < np2 / 2; t += nt) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // greedy pass over the sorted order; `dead` is indexed by ORIGINAL detection index
+    for (int i = 0; i < n; ++i) {
+        const unsigned ji = (unsigned)(key[i] & 0xffffffffu);
+        if (ji >= (unsigned)n || dead[ji]) { __syncthreads(); if (ji >= (unsigned)n) break; continue; }
+        const float si = by_obj ? objectness[ji] : prob[(size_t)ji * classes + k];
+        if (si == 0.f) { __syncthreads(); if (by_obj) continue; else continue; }
+        const float4 a = boxes[ji];
+        for (int jj = i + 1 + tid; jj < n; jj += nt) {
+            const unsigned j = (unsigned)(key[jj] & 0xffffffffu);
+            if (j >= (unsigned)n || dead[j]) continue;
+            if (by_obj && objectness[j] == 0.f) continue;
+            if (iou_darknet(a, boxes[j]) > thresh) {
+                if (by_obj) { objectness[j] = 0.f; for (int c = 0; c < classes; ++c) prob[(size_t)j * classes + c] = 0.f; }
+                else prob[(size_t)j * classes + k] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_nms_dets(const float4 *boxes, float *prob, float *objectness, int n, int classes, float thresh, int by_obj, hipStream_t s)
+{
+    if (n < 1) return hipSuccess;
+    if (n > NMSD_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_nms_dets, dim3(by_obj ? 1 : classes), dim3(1024), 0, s, boxes, prob, objectness, n, classes, thresh, by_obj);
+    return hipGetLastError();
+}

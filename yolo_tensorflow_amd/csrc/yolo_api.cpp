@@ -866,7 +866,7 @@ int yolo_forward(yolo_ctx *c, const void *images, int n, int fmt, int loc, float
 {
     if (!c) return YOLO_ERR_INVALID;
     if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward before weights were loaded");
-    if (fmt != YOLO_IMG_U8 && fmt != YOLO_IMG_F32) return fail(c, YOLO_ERR_INVALID, "bad image format");
+    if (fmt != YOLO_IMG_U8 && fmt != YOLO_IMG_F32 && fmt != YOLO_IMG_F32_CHW) return fail(c, YOLO_ERR_INVALID, "bad image format");
     HIPCK(c, hipSetDevice(c->device));
     int r = stage_in(c, images, n, fmt, loc, scale); if (r) return r;
     r = run_network(c, n); if (r) return r;
@@ -887,6 +887,25 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
     }
     hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
+    if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
+    if (r) return r;
+    if (det_out) return copy_out(c, det_out, c->d_det, (size_t)c->rows * c->attrs * 4, out_loc);
+    return YOLO_OK;
+}
+
+int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h, int loc, float *det_out, int out_loc)
+{
+    if (!c) return YOLO_ERR_INVALID;
+    if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward_letterbox_chw before weights were loaded");
+    if (!image_chw || h < 1 || w < 1) return fail(c, YOLO_ERR_INVALID, "bad image");
+    HIPCK(c, hipSetDevice(c->device));
+    const float *src = image_chw; void *tmp = nullptr;
+    if (loc == YOLO_HOST) {
+        HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3 * 4));
+        HIPCK(c, hipMemcpyAsync(tmp, image_chw, (size_t)h * w * 3 * 4, hipMemcpyHostToDevice, c->stream)); src = (const float *)tmp;
+    }
+    hipError_t e = launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
+    int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "letterbox: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
     if (det_out) return copy_out(c, det_out, c->d_det, (size_t)c->rows * c->attrs * 4, out_loc);
@@ -1298,6 +1317,20 @@ int yolo_op_detections_boxes(const float *det, int n, int rows, int attrs, float
     if (S.rc) return S.rc;
     if (!S.ok(launch_boxes_to_corners(d_i, d_o, (size_t)n * rows, attrs, S.s))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, cnt * 4);
+}
+
+int yolo_op_nms_detections(const float *boxes_xywh, float *prob, float *objectness, int n, int classes, float thresh, int by_objectness, int device)
+{
+    if (n == 0) return YOLO_OK;
+    if (!boxes_xywh || !prob || !objectness || n < 0 || classes < 1) { g_op_err = "nms_detections: bad arguments"; return YOLO_ERR_INVALID; }
+    if (n > 4096) { g_op_err = "nms_detections: more than 4096 detections"; return YOLO_ERR_UNSUPPORTED; }
+    OpScope S(device); if (S.rc) { g_op_err = "nms_detections: no HIP device"; return S.rc; }
+    float4 *d_b = (float4 *)S.upload(boxes_xywh, (size_t)n * 16);
+    float *d_p = (float *)S.upload(prob, (size_t)n * classes * 4), *d_o = (float *)S.upload(objectness, (size_t)n * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_nms_dets(d_b, d_p, d_o, n, classes, thresh, by_objectness ? 1 : 0, S.s))) { g_op_err = S.err; return S.rc; }
+    S.download(prob, d_p, (size_t)n * classes * 4);
+    return S.download(objectness, d_o, (size_t)n * 4);
 }
 
 int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out, int nms_mode,

@@ -16,7 +16,7 @@ BF16, FP32, FP8 = 0, 1, 2
 SEM_TF, SEM_DARKNET = 0, 1
 DECODE_RATIO, DECODE_PIXEL = 0, 1
 HOST, DEVICE = 0, 1
-IMG_U8, IMG_F32 = 0, 1
+IMG_U8, IMG_F32, IMG_F32_CHW = 0, 1, 2
 NMS_TF, NMS_PER_CLASS, NMS_DARKNET, NMS_NUMPY_V3 = 0, 1, 2, 3
 SELECT_GT, SELECT_GE = 0, 1
 
@@ -28,7 +28,7 @@ EXPORTS = [
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
-    "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_decode", "yolo_op_postprocess",
+    "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
 ]
 
 
@@ -88,6 +88,8 @@ def load_library():
     l.yolo_op_maxpool.argtypes = [P, I, I, I, I, I, I, P, I]
     l.yolo_op_resize_u8.argtypes = [P, I, I, I, F, P, I]
     l.yolo_op_detections_boxes.argtypes = [P, I, I, I, P, I]
+    l.yolo_op_nms_detections.argtypes = [P, P, P, I, I, F, I, I]
+    l.yolo_forward_letterbox_chw.argtypes = [P, P, I, I, I, P, I]
     l.yolo_op_decode.argtypes = [P, I, I, I, I, P, I, I, I, P, I]
     l.yolo_op_postprocess.argtypes = [P, I, I, I, F, F, I, I, I, P, P, I]
     _lib = l
@@ -337,6 +339,14 @@ def op_resize_u8(img, size, post_scale=1.0, device=0):
     out = np.empty((size, size, 3), dtype=np.float32)
     _op_check(load_library().yolo_op_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], size, post_scale, out.ctypes.data, device), "yolo_op_resize_u8")
     return out
+
+
+def op_nms_detections(boxes_xywh, prob, objectness, thresh, by_objectness=False, device=0):
+    """darknet do_nms_sort / do_nms_obj on arrays; returns (prob, objectness) after suppression."""
+    b = _f32(boxes_xywh); p = _f32(prob).copy(); o = _f32(objectness).copy()
+    n, classes = p.shape
+    _op_check(load_library().yolo_op_nms_detections(b.ctypes.data, p.ctypes.data, o.ctypes.data, n, classes, thresh, 1 if by_objectness else 0, device), "yolo_op_nms_detections")
+    return p, o
 
 
 def op_detections_boxes(det, device=0):
