@@ -99,12 +99,13 @@ def main():
     lo, hi = ydist.shard_bounds(B * G, G, rank)
     rng = np.random.default_rng(1 + rank)
     images = torch.from_numpy(rng.integers(0, 256, (hi - lo, args.size, args.size, 3), dtype=np.uint8)).to(dev)
-    boxes = torch.zeros((B, max_out * 6), dtype=torch.int32, device=dev)
-    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
-    # exchange buffers: every rank contributes its [B, max_out] box records and [B] counts, all ranks end up with the
-    # global batch in image order (equal shards -> all_gather_into_tensor straight from the library's output buffers)
-    boxes_all = torch.empty((B * G, max_out * 6), dtype=torch.int32, device=dev)
-    counts_all = torch.empty((B * G,), dtype=torch.int32, device=dev)
+    # one flat record buffer per rank: [B * max_out] box records (6 x int32 each) followed by [B] counts, written in place by
+    # the library, so the exchange is ONE all_gather_into_tensor straight from the library's output (equal shards: every
+    # rank ends up with the global batch in rank order)
+    rec = torch.zeros((B * max_out * 6 + B,), dtype=torch.int32, device=dev)
+    boxes = rec[:B * max_out * 6].view(B, max_out * 6)
+    counts = rec[B * max_out * 6:]
+    rec_all = torch.empty((G, B * max_out * 6 + B), dtype=torch.int32, device=dev)
     eng.forward(images, want_detections=False)
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
     tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, args.dtype))
@@ -132,8 +133,7 @@ def main():
             eng.detect_graph(images, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF,
                              select_mode=hip.SELECT_GT)
         if G > 1 or force_dist:
-            dist.all_gather_into_tensor(boxes_all, boxes)
-            dist.all_gather_into_tensor(counts_all, counts)
+            dist.all_gather_into_tensor(rec_all, rec)
         return None
 
     for _ in range(args.warmup):
