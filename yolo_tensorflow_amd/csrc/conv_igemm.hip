@@ -230,11 +230,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // (8-wave shapes only: in the 4-wave 176x128 shapes the extra live registers push the kernel past 256 VGPRs and cost the
     // second resident workgroup per CU -- measured slower overall even where the pair itself got faster)
     constexpr bool TAIL_OK = EB == 2 && !DIAG && WP == 1 && NC == 8 && NC * 16 == BC / 2;
-    // SPREAD: place one LDS-DMA of the next stage behind every MFMA group instead of issuing the whole stage first
-    // (possible when the loads sit in the MFMAs' basic block: every wave loads, scalar tap cursor).  Measured A/B on one
-    // MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms) and fp8 (2.39 vs 2.34 ms) -- a DMA
-    // blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe holds no queue to ride it out.
-    constexpr bool SPREAD = false;
+    // (Tried and dropped: placing one LDS-DMA of the next stage behind every MFMA group with sched_group_barrier instead of
+    // issuing the whole stage first.  A/B on one MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms)
+    // and fp8 (2.39 vs 2.34 ms) -- a DMA blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe
+    // holds no queue to ride it out.)
     constexpr int D = NS - 1;                  // prefetch distance in K-steps
 #pragma unroll
     for (int t = 0; t < D; ++t)
@@ -302,9 +301,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int j = 0; j < TP; ++j) {
                     if (j + PD < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
-                    // one LDS-DMA of the next stage behind each MFMA group: its ~60-cycle issue overlaps the MFMAs
-                    // already queued instead of preceding all of them
-                    if (SPREAD && LOAD && j < L) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 }
             }
         } else if (is_consumer) {
@@ -345,7 +341,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
-                if (SPREAD && LOAD && (g & 1) && (g >> 1) < L) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
         }
         if (DIAG) {

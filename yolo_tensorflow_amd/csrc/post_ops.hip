@@ -619,20 +619,22 @@ __global__ __launch_bounds__(1024) void k_nms_dets(const float4 *boxes, float *p
             }
             __syncthreads();
         }
-    // greedy pass over the sorted order; `dead` is indexed by ORIGINAL detection index
+    // greedy pass over the sorted order (every condition below is uniform across the workgroup: it only reads shared /
+    // global state that was last written before a barrier).  `dead` is indexed by ORIGINAL detection index.
     for (int i = 0; i < n; ++i) {
         const unsigned ji = (unsigned)(key[i] & 0xffffffffu);
-        if (ji >= (unsigned)n || dead[ji]) { __syncthreads(); if (ji >= (unsigned)n) break; continue; }
-        const float si = by_obj ? objectness[ji] : prob[(size_t)ji * classes + k];
-        if (si == 0.f) { __syncthreads(); if (by_obj) continue; else continue; }
-        const float4 a = boxes[ji];
-        for (int jj = i + 1 + tid; jj < n; jj += nt) {
-            const unsigned j = (unsigned)(key[jj] & 0xffffffffu);
-            if (j >= (unsigned)n || dead[j]) continue;
-            if (by_obj && objectness[j] == 0.f) continue;
-            if (iou_darknet(a, boxes[j]) > thresh) {
-                if (by_obj) { objectness[j] = 0.f; for (int c = 0; c < classes; ++c) prob[(size_t)j * classes + c] = 0.f; }
-                else prob[(size_t)j * classes + k] = 0.f;
+        if (ji >= (unsigned)n) break;                                   // only padding from here on
+        const float si = dead[ji] ? 0.f : (by_obj ? objectness[ji] : prob[(size_t)ji * classes + k]);
+        if (si != 0.f) {
+            const float4 a = boxes[ji];
+            for (int jj = i + 1 + tid; jj < n; jj += nt) {
+                const unsigned j = (unsigned)(key[jj] & 0xffffffffu);
+                if (j >= (unsigned)n || dead[j]) continue;
+                if (by_obj && objectness[j] == 0.f) continue;
+                if (iou_darknet(a, boxes[j]) > thresh) {
+                    if (by_obj) { objectness[j] = 0.f; for (int c = 0; c < classes; ++c) prob[(size_t)j * classes + c] = 0.f; }
+                    else prob[(size_t)j * classes + k] = 0.f;
+                }
             }
         }
         __syncthreads();
