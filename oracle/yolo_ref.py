@@ -16,7 +16,11 @@ tests/test_oracle_*.py:
     container, golden vectors committed;
   * `resize_bilinear` (legacy), `_upsample`, `space_to_depth`, `tf.image.non_max_suppression`:
     **parity unpinned** by any reference artefact -- restated from the TF-1.x kernel semantics and
-    checked against hand-derived closed forms only.
+    checked against hand-derived closed forms only;
+  * `to_fp8_e4m3`, `fp8_scheme_forward`, `fp8_calibrate_scales` (BASELINE config 5): **parity unpinned** --
+    the reference has no reduced-precision path at all, so the quantisation scheme is defined by this repo
+     and restated here; the e4m3 rounding itself is checked exhaustively against the OCP
+    value table (tests/test_oracle_closed_forms.py).
 
 Layout convention: activations NHWC float32 (the reference's `data_format='NHWC'` path), conv
 weights HWIO, exactly as the TF graph holds them after `load_weights`.
