@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     }
 
     // K cursor.  UNI: scalars (tap, kh, kw, channel base).  Otherwise per lane (chunk-dependent).
-    int s_tap = 0, s_kh = 0, s_kw = 0, s_kb = 0;        // UNI
+    int s_tap = 0, s_kh = 0, s_kw = 0, s_kb = 0, s_cb = 0;   // UNI: tap, its (kh, kw), channel offset in the chunk, chunk base
     int v_kc = chunk * EPC, v_tap = 0;                  // !UNI
     if (!UNI)
         while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
@@ -184,8 +184,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         char *dx = sbase + wid * 1024;
         char *dw = sbase + BPL * RB + wid * 1024;
         if (UNI) {
-            const unsigned tapbit = s_tap < KK ? 1u << s_tap : 0u;
-            const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_kb) * EB;
+            // K order: channel chunks of a.kchunk outermost, the taps inside a chunk, the chunk's channels innermost
+            // (k = (chunk * KK + tap) * kchunk + c).  Consecutive K-steps then read the SAME channels of neighbouring
+            // pixels -- 175 of a tile's 176 rows are the rows of the previous tap shifted by one pixel -- so the re-reads
+            // hit the CU's vector L1 instead of going back to L2 (with tap-outermost order the reuse distance was a whole
+            // tap, 4-8 K-steps).
+            const unsigned tapbit = s_cb < a.Cin_pad ? 1u << s_tap : 0u;
+            const int soff = ((s_kh * a.W + s_kw) * a.in_stride + s_cb + s_kb) * EB;
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 const unsigned vo = (tapmask[i] & tapbit) ? rowoff[i] : OOB_OFFSET;
@@ -194,10 +199,12 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // branch-free cursor update (a branch here would split the K-step into basic blocks and keep the scheduler
             // from placing these loads between the MFMAs)
             s_kb += BKE;
-            const int w1 = s_kb >= a.Cin_pad ? 1 : 0;
+            const int w1 = s_kb >= a.kchunk ? 1 : 0;
             s_kb = w1 ? 0 : s_kb; s_tap += w1; s_kw += w1;
             const int w2 = s_kw == a.ksize ? 1 : 0;
             s_kw = w2 ? 0 : s_kw; s_kh += w2;
+            const int w3 = s_tap == KK ? 1 : 0;
+            s_tap = w3 ? 0 : s_tap; s_kh = w3 ? 0 : s_kh; s_cb += w3 ? a.kchunk : 0;
         } else {
             int kh = 0, kw = 0;
             if (a.ksize == 3) { kh = (v_tap * 11) >> 5; kw = v_tap - kh * 3; }

@@ -42,12 +42,16 @@ struct ConvArgs {
     int Ho, Wo, Cout;
     int ksize, stride, pad;
     int Kpad;                            // multiple of 64 (bf16) / 128 (fp8) elements
+    int kchunk;                          // channels per K-order chunk: k = (chunk * k*k + tap) * kchunk + c (conv_kchunk())
     int act;
     const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
     // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
     uint32_t howo_mul, howo_shift, wo_mul, wo_shift;
     unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
 };
+// K-order chunk of a conv whose filters are stored with `wdt` elements: one 128-byte LDS row of channels when the padded
+// channel count is a multiple of that, else all channels (i.e. plain tap-major order); fp32 filters keep tap-major order
+inline int conv_kchunk(int cin_pad, int wdt) { const int row = wdt == DT_FP8 ? 128 : 64; return (wdt != DT_F32 && cin_pad % row == 0) ? row : cin_pad; }
 // host helper: derives the division constants from Ho, Wo (call after filling the geometry)
 inline void conv_finalize(ConvArgs &a)
 {

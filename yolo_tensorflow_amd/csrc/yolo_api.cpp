@@ -437,7 +437,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
         } else a.out_inv_scale = 1.f / c->eff_scale[li];
     }
     a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
-    a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = L.act; a.zeros = c->d_zeros;
+    a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, L.in_dt); a.act = L.act; a.zeros = c->d_zeros;
     conv_finalize(a);
     return a;
 }
@@ -607,7 +607,8 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < k * k; ++t) {
                 const float v = row[(size_t)ci * k * k + t];
-                const size_t idx = (size_t)o * L.kpad + (size_t)t * L.cin_pad + ci;        // t = kh * k + kw
+                const int kc = conv_kchunk(L.cin_pad, wdt);                              // K order: see conv_igemm.hip `stage`
+                const size_t idx = (size_t)o * L.kpad + ((size_t)(ci / kc) * k * k + t) * kc + ci % kc;     // t = kh * k + kw
                 if (wdt == DT_F32) memcpy(&wbuf[idx * 4], &v, 4);
                 else if (wdt == DT_FP8) wbuf[idx] = f2e4m3(v / osc[o]);
                 else { uint16_t b = f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
@@ -757,6 +758,7 @@ int yolo_load_darknet_weights(yolo_ctx *c, const char *path, int header_ints)
 namespace {
 struct ArtHeader { char magic[8]; uint32_t version, dtype, semantics, decode, n_layers, num_cfgs, cfg_len, reserved; };
 const char kArtMagic[8] = {'Y', 'O', 'L', 'O', 'H', 'I', 'P', '1'};
+const uint32_t kArtVersion = 2;          // 2: filters packed chunk-major (conv_kchunk); a version-1 file holds tap-major filters
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
 struct ArtWriter {
     FILE *f; uint64_t h = 1469598103934665603ull; bool ok = true;
@@ -778,7 +780,7 @@ int yolo_export(yolo_ctx *c, const char *path)
     ArtWriter w{f};
     const uint32_t NL = (uint32_t)c->layers.size();
     ArtHeader hd; memset(&hd, 0, sizeof hd); memcpy(hd.magic, kArtMagic, 8);
-    hd.version = 1; hd.dtype = c->dtype; hd.semantics = c->semantics; hd.decode = c->decode; hd.n_layers = NL;
+    hd.version = kArtVersion; hd.dtype = c->dtype; hd.semantics = c->semantics; hd.decode = c->decode; hd.n_layers = NL;
     hd.num_cfgs = (uint32_t)conv_num_cfgs(); hd.cfg_len = (uint32_t)c->cfg_text.size();
     w.put(&hd, sizeof hd); w.put(c->cfg_text.data(), c->cfg_text.size());
     std::vector<float> sc(c->user_scale); sc.resize(NL, 1.f); w.put(sc.data(), NL * 4);
@@ -809,7 +811,7 @@ yolo_ctx *yolo_create_from_file(const char *path, int max_batch, int device, voi
     if (!f) return bail(nullptr, std::string("cannot open '") + (path ? path : "(null)") + "'");
     ArtReader r{f};
     ArtHeader hd; r.get(&hd, sizeof hd);
-    if (!r.ok || memcmp(hd.magic, kArtMagic, 8) != 0 || hd.version != 1 || hd.cfg_len > (1u << 24) || hd.n_layers > 4096) { fclose(f); return bail(nullptr, "not a YOLOHIP1 artifact (or an unsupported version)"); }
+    if (!r.ok || memcmp(hd.magic, kArtMagic, 8) != 0 || hd.version != kArtVersion || hd.cfg_len > (1u << 24) || hd.n_layers > 4096) { fclose(f); return bail(nullptr, "not a YOLOHIP1 artifact (or an unsupported version)"); }
     std::string cfg_text(hd.cfg_len, '\0'); r.get(&cfg_text[0], hd.cfg_len);
     std::vector<float> sc(hd.n_layers); r.get(sc.data(), (size_t)hd.n_layers * 4);
     std::vector<int32_t> plan(hd.n_layers); r.get(plan.data(), (size_t)hd.n_layers * 4);
@@ -1230,7 +1232,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     a.in = d_x; a.in_stride = L.cin_pad; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = cstride; a.out_dt = dt; a.in_dt = dt;
     a.oscale = d_sc; a.out_inv_scale = a.res_scale = a.mid_scale = a.mid_inv_scale = 1.f;
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
-    a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.act = act; a.zeros = d_z;
+    a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, dt); a.act = act; a.zeros = d_z;
     conv_finalize(a);
     hipError_t e;
     if (dt != DT_F32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
