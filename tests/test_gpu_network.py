@@ -305,29 +305,37 @@ def test_fused_plan_equals_layer_by_layer_plan(hiplib, size):
     assert np.array_equal(dets[0], dets[1])
 
 
-def test_fused_1x1_tail_equals_separate_launch(hiplib):
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp8"])
+def test_fused_1x1_tail_equals_separate_launch(hiplib, dtype_name):
     """A 1x1 conv folded into the epilogue of the 3x3 conv that feeds it (tile plan code cfg + 10000) gives the same
-    bits as the two separate launches, on every producer the planner marks as fusable (with and without a shortcut)."""
+    bits as the two separate launches, on every producer the planner marks as fusable (with and without a shortcut),
+    in the bf16 and in the fp8 configuration (there with non-trivial activation scales)."""
+    dtype = hiplib.BF16 if dtype_name == "bf16" else hiplib.FP8
     size = 160
     txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
     secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=5)
     img = np.random.default_rng(9).integers(0, 256, (2, size, size, 3), dtype=np.uint8)
-    ref = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16, keep_layers=True)
+    scales = np.ones(len(secs) - 1, np.float32); scales[::2] = 0.5; scales[1::4] = 0.25
+    ref = hiplib.Engine(txt, max_batch=2, dtype=dtype, keep_layers=True)
+    if dtype == hiplib.FP8:
+        ref.set_act_scales(scales)
     ref.set_weights(flat); want = ref.forward(img); ref.close()
-    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16)
+    eng = hiplib.Engine(txt, max_batch=2, dtype=dtype)
+    if dtype == hiplib.FP8:
+        eng.set_act_scales(scales)
     eng.set_weights(flat)
     cfgs = np.full(eng.num_layers, -1, np.int32)
     fused = 0
     for i, s in enumerate(secs[1:]):
         if s["type"] != "convolutional" or int(s["filters"]) not in (128, 256):
             continue
-        trial = cfgs.copy(); trial[i] = (32 if int(s["filters"]) == 256 else 16) + 10000
+        trial = cfgs.copy(); trial[i] = 32 + 10000
         try:
             eng.set_tile_configs(trial)
             cfgs = trial; fused += 1
         except hiplib.YoloError:
             pass                                            # not followed by a foldable 1x1 conv
-    assert fused >= 10                                      # 2 at 104x104, 8 + 2 at 52x52
+    assert fused >= 10                                      # 8 + 2 producers with 256 channels (the 52x52-style stages)
     eng.set_tile_configs(cfgs)
     assert np.array_equal(eng.get_tile_configs()[cfgs >= 0], cfgs[cfgs >= 0])
     got = eng.forward(img)

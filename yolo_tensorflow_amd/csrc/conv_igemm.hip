@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // consumer waves split the C2 = BC / 2 tail channels 16 apiece
     // (8-wave shapes only: in the 4-wave 176x128 shapes the extra live registers push the kernel past 256 VGPRs and cost the
     // second resident workgroup per CU -- measured slower overall even where the pair itself got faster)
-    constexpr bool TAIL_OK = EB == 2 && !DIAG && WP == 1 && NC == 8 && NC * 16 == BC / 2;
+    constexpr bool TAIL_OK = !DIAG && WP == 1 && NC == 8 && NC * 16 == BC / 2;
     // (Tried and dropped: placing one LDS-DMA of the next stage behind every MFMA group with sched_group_barrier instead of
     // issuing the whole stage first.  A/B on one MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms)
     // and fp8 (2.39 vs 2.34 ms) -- a DMA blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         }
         // fused 1x1 tail: its filter fragments (16 rows x BC per consumer wave) are fetched here when the registers allow
         // (8-wave shapes), so their latency hides behind the epilogue; the 4-wave shapes fetch them just before use
-        constexpr bool TAIL_EARLY = TAIL_OK && NL == 0;       // the 12-wave role-split shape has no registers to spare
-        bf16x8 fw2[TAIL_OK ? BC / 32 : 1];
+        constexpr bool TAIL_EARLY = TAIL_OK && NL == 0 && EB == 2;   // the 12-wave role-split shape has no registers to spare
+        bf16x8 fw2[TAIL_OK && EB == 2 ? BC / 32 : 1];
         if (TAIL_EARLY) if (a.w2 && is_consumer)
 #pragma unroll
             for (int kk = 0; kk < BC / 32; ++kk)
@@ -479,6 +479,58 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     pw[q] = f32x2_to_fp8<true>(v[4 * q + 2] * a.out_inv_scale, v[4 * q + 3] * a.out_inv_scale,
                                                f32x2_to_fp8<false>(v[4 * q] * a.out_inv_scale, v[4 * q + 1] * a.out_inv_scale, 0));
                 *(uint4 *)((char *)a.out + (size_t)m * a.out_stride + ch) = uint4{pw[0], pw[1], pw[2], pw[3]};
+                if (TAIL_OK && EB == 1) if (a.w2) *(uint4 *)(smem + BP * RS + row * (BC + 16) + cc * 16) = uint4{pw[0], pw[1], pw[2], pw[3]};
+            }
+            if constexpr (TAIL_OK && EB == 1) if (a.w2) {
+                // ---- fused 1x1 tail, e4m3 form: the codes just stored are also kept in LDS ([BP][BC] bytes, pitch BC + 16);
+                //      wave w owns tail channels 16w..16w+15; K = BC codes in 128-wide steps on the fp8 MFMA with the same
+                //      chunk assignment (lq, lq + 4) as the main loop; epilogue = the stand-alone fp8 kernel's: acc * osc + b,
+                //      leaky, bf16 rounding, e4m3(v / scale).  Bit-identical to the separate launch. ----
+                constexpr int C2 = BC / 2, K2S = BC / 128, RSC = BC + 16, RS2 = C2 + 16;
+                const char *const codes = smem + BP * RS;
+                char *const st2 = smem;                            // the bf16 tile is dead once the store loop has run
+                i32x8 fw2q[K2S];
+                if (is_consumer)
+#pragma unroll
+                    for (int kk = 0; kk < K2S; ++kk) {
+                        const char *wr = (const char *)a.w2 + (size_t)(wave_id * 16 + l15) * a.K2pad + kk * 128;
+                        const uint4 lo = *(const uint4 *)(wr + lq * 16), hi = *(const uint4 *)(wr + (lq + 4) * 16);
+                        fw2q[kk] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                block_barrier();
+                if (is_consumer) {
+                    const float4 b2v = *(const float4 *)(a.b2 + wave_id * 16 + lq * 4);
+                    const float4 s2v = *(const float4 *)(a.oscale2 + wave_id * 16 + lq * 4);
+#pragma unroll 1
+                    for (int j = 0; j < TP; ++j) {
+                        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < K2S; ++kk) {
+                            const char *xr = codes + (j * 16 + l15) * RSC + kk * 128;
+                            const uint4 lo = *(const uint4 *)(xr + lq * 16), hi = *(const uint4 *)(xr + (lq + 4) * 16);
+                            const i32x8 x = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                            acc2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw2q[kk], x, acc2, 0, 0, 0, 0, 0, 0);
+                        }
+                        float v[4] = {acc2[0] * s2v.x + b2v.x, acc2[1] * s2v.y + b2v.y, acc2[2] * s2v.z + b2v.z, acc2[3] * s2v.w + b2v.w};
+                        if (a.act2 == ACT_LEAKY) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = bf16_bits_to_f32(f32_to_bf16_rn(v[q])) * a.out2_inv_scale;
+                        const uint32_t w8 = f32x2_to_fp8<true>(v[2], v[3], f32x2_to_fp8<false>(v[0], v[1], 0));
+                        *(uint32_t *)(st2 + (j * 16 + l15) * RS2 + wave_id * 16 + lq * 4) = w8;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                block_barrier();
+                constexpr int CPR2 = C2 / 16;
+                for (int c = tid; c < BP * CPR2; c += NT) {
+                    const int row = c / CPR2, cc = c - row * CPR2;
+                    const int m = pt * BP + row;
+                    if (m < M) *(uint4 *)((char *)a.out2 + (size_t)m * a.out2_stride + cc * 16) = *(const uint4 *)(st2 + row * RS2 + cc * 16);
+                }
             }
         } else {
 #pragma unroll
@@ -500,11 +552,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
                     }
                     o = uint4{ov[0], ov[1], ov[2], ov[3]};
-                    if (TAIL_OK && a.w2) *(uint4 *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
+                    if (TAIL_OK && EB == 2 && a.w2) *(uint4 *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                 }
                 *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
             }
-            if (TAIL_OK) if (a.w2) {
+            if constexpr (TAIL_OK && EB == 2) if (a.w2) {
                 // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.
                 //      Consumer wave w owns output channels 16w..16w+15 for every pixel of the tile; its filter fragments
                 //      (16 rows x BC, 8 KB) come straight from global; K is walked in ascending 32-wide steps, the order of

@@ -38,6 +38,7 @@ struct ConvArgs {
     // computed from the finished output tile while it is still in LDS (the 1x1 conv that follows a 3x3 in every darknet
     // residual block).  w2 == nullptr: none.  C2 = Cout / 2, W2 packed [C2 pad][K2pad], k = channel of `out`.
     const void *w2; const float *b2; void *out2; int out2_stride, K2pad, act2;
+    const float *oscale2; float out2_inv_scale;      // fp8 tail: per-channel dequantisation scale of W2, 1 / scale of out2
     int N, H, W, Cin_pad;
     int Ho, Wo, Cout;
     int ksize, stride, pad;

@@ -285,7 +285,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
-    if (c->dtype == YOLO_BF16 && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
+    if ((c->dtype == YOLO_BF16 || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
             if (P.type != L_CONV || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
@@ -429,6 +429,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     if (L.tail_on && L.tail_layer >= 0) {
         const Layer &T = c->layers[L.tail_layer];
         a.w2 = T.d_w; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
+        a.oscale2 = T.d_sc; a.out2_inv_scale = T.out.dt == DT_FP8 ? 1.f / c->eff_scale[L.tail_layer] : 1.f;
     }
     if (L.out.dt == DT_FP8) {
         if (L.residual_from >= -1) {     // fused shortcut: this conv writes layer li+1's tensor
@@ -469,6 +470,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_fp8(a, cfg, s));
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
