@@ -248,6 +248,168 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo-staged 3x3/s1 conv for a SMALL channel count (Cin = 32 -> Cout = 64, + bias, leaky/linear, optional shortcut):
+// darknet-53 layer 3.  In the tiled kernel every input pixel crosses the L2 -> LDS path nine times (once per tap) and
+// a K of 288 is nine short K-steps per tile; here the 10 x 18 input pixels of an 8 x 16 output tile (64 B each) are
+// gathered into LDS ONCE by LDS-DMA, one tile ahead, and the nine taps are nine ds_read_b128 at shifted addresses against
+// register-resident filters -- the phase-B structure of the stem kernel above with stride 1.  The shortcut source tile is
+// DMA'd into LDS at the start of its tile and added in the store pass (conv output rounded to bf16 first, as everywhere).
+// LDS pixel records are 64 B with the 16-B chunk index XOR 2*((pixel>>2)&1): conflict-free for ds_read_b128's lane groups
+// at pixel stride 1.  HBM-bound by design: input once, shortcut once, output once.
+constexpr int HL_IH = ST_TH + 2, HL_IW = ST_TW + 2;          // 10 x 18 input pixels
+constexpr int HL_INPIX = HL_IH * HL_IW;                      // 180
+constexpr int HL_INCHUNKS = (HL_INPIX * 4 + 63) / 64;        // 16-B pieces / 64 lanes: 12 LDS-DMA instructions
+constexpr int HL_IN_BYTES = HL_INCHUNKS * 1024;
+constexpr int HL_RES_BYTES = ST_TH * ST_TW * 128;            // shortcut tile [128 px][64 bf16], lane-linear
+
+__global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    bf16x8 fw[4][9];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            fw[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w + (size_t)(ct * 16 + l15) * a.Kpad + t * 32 + lq * 8);
+    float4 bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const float4 *)(a.b + ct * 16 + lq * 4);
+
+    const int tiles_x = (a.W + ST_TW - 1) / ST_TW, tiles_y = (a.H + ST_TH - 1) / ST_TH;
+    const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0x80000000u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res ? a.res : a.in), 0, 0x80000000u, 0x00020000);
+
+    auto fetch_in = [&](int tile, char *dst) {
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int iy0 = ty * ST_TH - 1, ix0 = tx * ST_TW - 1;
+#pragma unroll
+        for (int k = 0; k < (HL_INCHUNKS + ST_NW - 1) / ST_NW; ++k) {
+            const int c = wave + ST_NW * k;
+            if (c < HL_INCHUNKS) {
+                const int q = c * 64 + lane;                     // 16-B piece: pixel q >> 2, physical chunk q & 3
+                const int px = q >> 2, pc = q & 3;
+                const int ry = (px * 3641) >> 16;                // px / 18 for px < 192
+                const int rxx = px - ry * HL_IW;
+                const int iy = iy0 + ry, ix = ix0 + rxx;
+                const int sc = pc ^ (2 * ((px >> 2) & 1));       // source chunk that belongs in this physical slot
+                const bool ok = px < HL_INPIX && tile < ntiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.in_stride + sc * 8) * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (st_lds_void *)(dst + c * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto fetch_res = [&](int tile, char *dst) {                  // [128 px][8 pieces], linear
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = (wave + ST_NW * k) * 64 + lane;
+            const int px = q >> 3, pc = q & 7;
+            const int oy = ty * ST_TH + (px >> 4), ox = tx * ST_TW + (px & 15);
+            const bool ok = oy < a.H && ox < a.W;
+            const unsigned off = ok ? (unsigned)(((n * a.H + oy) * a.W + ox) * a.res_stride + pc * 8) * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, (st_lds_void *)(dst + (wave + ST_NW * k) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur,
+                       char *__restrict__ lres, char *__restrict__ lo) {
+        fetch_in(next_tile, in_next);
+        if (a.res) fetch_res(tile, lres);
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - kh * 3;
+            const int p = (wave + kh) * HL_IW + l15 + kw;        // input-tile pixel of this lane for this tap
+            const bf16x8 x = *(const bf16x8 *)(in_cur + p * 64 + ((lq ^ (2 * ((p >> 2) & 1))) << 4));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct][t], x, acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float v[4] = {acc[ct][0] + bv[ct].x, acc[ct][1] + bv[ct].y, acc[ct][2] + bv[ct].z, acc[ct][3] + bv[ct].w};
+            if (a.act == ACT_LEAKY)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
+            uint2 pk;
+            pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
+            pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = pk;
+        }
+        // staged tile complete, every wave done with this tile's input, next input and this tile's shortcut have landed
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < ST_TH * ST_TW * 8 / (64 * ST_NW); ++it) {
+            const int c = tid + it * 64 * ST_NW;
+            const int px = c >> 3, chunk = c & 7;
+            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+            uint4 o = *(const uint4 *)(lo + px * ST_OPITCH + chunk * 16);
+            if (a.res) {
+                const uint4 r = *(const uint4 *)(lres + c * 16);
+                uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo_ = __builtin_bit_cast(float, ov[q] << 16) + __builtin_bit_cast(float, rv[q] << 16);
+                    const float hi_ = __builtin_bit_cast(float, ov[q] & 0xffff0000u) + __builtin_bit_cast(float, rv[q] & 0xffff0000u);
+                    ov[q] = stem_bf16(lo_) | (stem_bf16(hi_) << 16);
+                }
+                o = uint4{ov[0], ov[1], ov[2], ov[3]};
+            }
+            if (oy < a.H && ox < a.W)
+                *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8) = o;
+        }
+        // the next tile writes `lo` / `lres` only after its own pre-store barrier / its fetch: `lres` is re-filled at the
+        // start of the next tile, so every thread must be past the reads above first
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    char *const inb0 = smem, *const inb1 = smem + HL_IN_BYTES;
+    char *const lres = smem + 2 * HL_IN_BYTES, *const lo = lres + HL_RES_BYTES;
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch_in(tile, inb0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, lres, lo);
+        else do_tile(tile, tile + gridDim.x, inb1, inb0, lres, lo);
+    }
+#endif
+}
+
+bool conv_halo_ok(const HaloArgs &a)
+{
+    return a.Cin == 32 && a.Cout == 64 && a.Kpad >= 288 && (a.in_stride % 8) == 0 && a.in_stride >= 32 && (a.out_stride % 8) == 0 &&
+           a.out_stride >= 64 && (!a.res || ((a.res_stride % 8) == 0 && a.res_stride >= 64));
+}
+hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s)
+{
+    if (!conv_halo_ok(a)) return hipErrorInvalidValue;
+    static bool done = false;
+    const size_t lds = (size_t)2 * HL_IN_BYTES + HL_RES_BYTES + ST_OUT_BYTES;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv_halo_c32_c64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const long tiles = (long)a.N * ((a.W + ST_TW - 1) / ST_TW) * ((a.H + ST_TH - 1) / ST_TH);
+    long blocks = 256; if (blocks > tiles) blocks = tiles;
+    hipLaunchKernelGGL(conv_halo_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    return hipGetLastError();
+}
+
 bool conv_stem_ok(const StemArgs &a)
 {
     return a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&

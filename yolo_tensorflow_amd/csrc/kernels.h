@@ -94,6 +94,16 @@ struct StemArgs {
 };
 bool conv_stem_ok(const StemArgs &a);
 hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s);
+// halo-staged 3x3/s1 conv, Cin = 32 -> Cout = 64, bf16, optional shortcut (conv_stem.hip)
+struct HaloArgs {
+    const void *in; int in_stride;            // [N,H,W,>=32] bf16
+    const void *w; const float *b; int Kpad, Cin, Cout, act;   // [Cout pad][Kpad], k = tap*32 + ci
+    const void *res; int res_stride;          // shortcut source [N,H,W,>=64] bf16 or nullptr
+    void *out; int out_stride;
+    int N, H, W;
+};
+bool conv_halo_ok(const HaloArgs &a);
+hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s);
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 

@@ -42,6 +42,7 @@ struct Layer {
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
+    bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one
     // fused 1x1 tail of the tiled conv kernel: `tail_layer` (on the producer) = index of the 1x1 conv that can be computed
     // in the producer's epilogue, `fused_into` (on that 1x1) = the producer; `tail_on` = the plan uses it
     int tail_layer = -1, fused_into = -1; bool tail_on = false;
@@ -283,6 +284,12 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             }
         }
     }
+    if (c->dtype == YOLO_BF16 && !getenv("YOLO_NO_HALO"))
+        for (int i = 1; i < NL; ++i) {
+            Layer &L = c->layers[i];
+            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64)
+                L.halo = true;
+        }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
     if ((c->dtype == YOLO_BF16 || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
@@ -467,6 +474,13 @@ int run_layer(yolo_ctx *c, int i, int n)
             break;
         }
         ConvArgs a = conv_args(c, L, n);
+        if (L.halo) {          // small-Cin 3x3: input tile staged once in LDS (conv_stem.hip)
+            HaloArgs h; memset(&h, 0, sizeof h);
+            h.in = a.in; h.in_stride = a.in_stride; h.w = a.wt; h.b = a.bias; h.Kpad = a.Kpad; h.Cin = L.cin; h.Cout = L.filters; h.act = L.act;
+            h.res = a.res; h.res_stride = a.res_stride; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = L.H; h.W = L.W;
+            HIPCK(c, launch_conv_halo(h, s));
+            break;
+        }
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
@@ -1072,7 +1086,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
-        if (L.stem || L.stem_skip || L.stem_tail) return false;                     // fused stem: nothing to choose
+        if (L.stem || L.stem_skip || L.stem_tail || L.halo) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
@@ -1080,7 +1094,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     };
     for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail && !c->layers[i].halo) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
@@ -1096,7 +1110,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         // a configuration a layer cannot launch (LDS / 2 GiB window) must not abort the pass: probe once
         for (int i = 0; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip || L.stem_tail) continue;
+            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip || L.stem_tail || L.halo) continue;
             ConvArgs a = conv_args(c, L, n);
             hipError_t e = a.in_dt == DT_FP8 ? launch_conv_fp8(a, cfg, c->stream) : launch_conv_bf16(a, cfg, c->stream);
             if (e != hipSuccess) { (void)hipGetLastError(); L.tile_cfg = fallback[i]; }
@@ -1104,17 +1118,17 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         int r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
         for (int i = 0; i < NL; ++i) {
             const Layer &L = c->layers[i];
-            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip && !L.stem_tail) score[shape_key(L)][cfg] += ms[i];
+            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip && !L.stem_tail && !L.halo) score[shape_key(L)][cfg] += ms[i];
         }
         if (getenv("YOLO_TUNE_VERBOSE")) {
             std::map<std::string, double> seen;
-            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
+            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail && !c->layers[i].halo) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
             for (auto &kv : seen) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms (sum over the layers of this shape, in situ)\n", kv.first.c_str(), cfg, conv_cfg_name(cfg), kv.second);
         }
     }
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type != L_CONV || L.stem || L.stem_skip || L.stem_tail) continue;
+        if (L.type != L_CONV || L.stem || L.stem_skip || L.stem_tail || L.halo) continue;
         auto it = score.find(shape_key(L));
         int best = fallback[i]; double bt = 1e30;
         if (it != score.end()) for (auto &kv : it->second) if (kv.second < bt) { bt = kv.second; best = kv.first; }
