@@ -102,10 +102,8 @@ def main():
     # one flat record buffer per rank: [B * max_out] box records (6 x int32 each) followed by [B] counts, written in place by
     # the library, so the exchange is ONE all_gather_into_tensor straight from the library's output (equal shards: every
     # rank ends up with the global batch in rank order)
-    rec = torch.zeros((B * max_out * 6 + B,), dtype=torch.int32, device=dev)
-    boxes = rec[:B * max_out * 6].view(B, max_out * 6)
-    counts = rec[B * max_out * 6:]
-    rec_all = torch.empty((G, B * max_out * 6 + B), dtype=torch.int32, device=dev)
+    rec, boxes, counts = ydist.alloc_flat_records(B, max_out, dev)
+    rec_all = torch.empty((G, rec.numel()), dtype=torch.int32, device=dev)
     eng.forward(images, want_detections=False)
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
     tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, args.dtype))
@@ -133,7 +131,7 @@ def main():
             eng.detect_graph(images, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF,
                              select_mode=hip.SELECT_GT)
         if G > 1 or force_dist:
-            dist.all_gather_into_tensor(rec_all, rec)
+            ydist.gather_flat_records(rec, out=rec_all)
         return None
 
     for _ in range(args.warmup):

@@ -54,3 +54,35 @@ def test_two_rank_gather_matches_single_process():
     for i in range(B):
         want, cnt = _fake_boxes(i, max_out)
         assert len(dets[i]) == cnt and np.array_equal(dets[i], want[:cnt])
+
+
+def _flat_worker(rank, world, port, n_local, max_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec, boxes, counts = ydist.alloc_flat_records(n_local, max_out, "cpu")
+    for i in range(n_local):                                  # what the library would have written in place
+        b, cnt = _fake_boxes(rank * n_local + i, max_out)
+        boxes[i] = torch.from_numpy(b.view(np.int32).reshape(-1)); counts[i] = cnt
+    rec_all = ydist.gather_flat_records(rec)
+    gb, gc = ydist.split_flat_records(rec_all, n_local, max_out)
+    q.put((rank, gb.numpy().copy(), gc.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_flat_record_exchange():
+    """The hot-path exchange of bench.py: equal shards, ONE collective on the flat [records | counts] buffer."""
+    n_local, max_out, world = 3, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, n_local, max_out, q)) for r in range(world)]
+    for p in procs: p.start()
+    results = {r: (b, c) for r, b, c in (q.get(timeout=120) for _ in range(world))}
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    gb, gc = results[0]
+    assert gb.shape == (world * n_local, max_out * 6) and gc.shape == (world * n_local,)
+    for i in range(world * n_local):
+        want, cnt = _fake_boxes(i, max_out)
+        assert gc[i] == cnt and np.array_equal(gb[i], want.view(np.int32).reshape(-1))

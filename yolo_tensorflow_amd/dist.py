@@ -61,3 +61,34 @@ def _all_gather_list(out, padded, world, per, group):
     import torch.distributed as dist
     parts = [out[r * per:(r + 1) * per] for r in range(world)]
     dist.all_gather(parts, padded, group=group)
+
+
+# ---- in-place exchange used on the hot path (bench.py): the library writes box records and counts straight into ONE
+#      flat int32 buffer per rank, which is all-gathered as is (equal shards) ----
+def alloc_flat_records(n_local, max_out, device):
+    """-> (rec, boxes, counts): rec int32 [n_local*max_out*6 + n_local]; boxes = rec's leading [n_local, max_out*6] view
+    (what yolo_detect* fills as yolo_box records), counts = its trailing [n_local] view."""
+    import torch
+    rec = torch.zeros((n_local * max_out * RECORD_FLOATS + n_local,), dtype=torch.int32, device=device)
+    return rec, rec[:n_local * max_out * RECORD_FLOATS].view(n_local, max_out * RECORD_FLOATS), rec[n_local * max_out * RECORD_FLOATS:]
+
+
+def gather_flat_records(rec, out=None, group=None):
+    """One collective: every rank's flat buffer -> [world, len(rec)] on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world, rec.numel()), dtype=rec.dtype, device=rec.device)
+    if rec.is_cuda:
+        dist.all_gather_into_tensor(out, rec, group=group)
+    else:
+        dist.all_gather([out[r] for r in range(world)], rec, group=group)
+    return out
+
+
+def split_flat_records(rec_all, n_local, max_out):
+    """[world, flat] -> (boxes [world*n_local, max_out*6], counts [world*n_local]) in rank (= image) order."""
+    world = rec_all.shape[0]
+    nb = n_local * max_out * RECORD_FLOATS
+    return rec_all[:, :nb].reshape(world * n_local, max_out * RECORD_FLOATS), rec_all[:, nb:].reshape(world * n_local)
