@@ -239,3 +239,30 @@ def test_postprocess_v2_numpy_flavour(hiplib):
         assert len(g) == len(ss) > 0
         assert np.array_equal(g["score"], ss.astype(np.float32)) and np.array_equal(g["cls"], cc)
         assert np.array_equal(np.stack([g["x0"], g["y0"], g["x1"], g["y1"]], -1).astype(np.int32), bb)
+
+
+def test_nms_detections_op_vs_oracle(hiplib):
+    """do_nms_sort semantics on caller arrays (yolo_op_nms_detections) against the oracle restatement of DN/box.c:58-89
+    (itself pinned to the compiled reference by tests/test_oracle_golden.py), including detections with objectness 0
+    (which must neither suppress nor be touched), a single detection and n = 0."""
+    rng = np.random.default_rng(33)
+    for n, classes in ((1, 3), (37, 5), (700, 20), (2500, 4)):
+        clusters = max(1, n // 12)
+        centres = rng.uniform(0.2, 0.8, (clusters, 2)).astype(np.float32)
+        which = rng.integers(0, clusters, n)
+        boxes = np.concatenate([centres[which] + rng.normal(0, 0.01, (n, 2)).astype(np.float32),
+                                rng.uniform(0.1, 0.2, (n, 2)).astype(np.float32)], 1).astype(np.float32)
+        prob = (rng.uniform(0, 1, (n, classes)) * (rng.uniform(0, 1, (n, classes)) > 0.5)).astype(np.float32)
+        obj = rng.uniform(0.1, 1, n).astype(np.float32)
+        obj[rng.uniform(0, 1, n) < 0.1] = 0.0
+        live = obj != 0
+        want = prob.copy()
+        want[live] = R.dn_nms_sort(boxes[live], prob[live], 0.45)
+        got_p, got_o = hiplib.op_nms_detections(boxes, prob, obj, 0.45)
+        assert np.array_equal(got_o, obj)
+        assert np.array_equal(got_p, want)
+        assert n < 30 or (got_p == 0).sum() > (prob == 0).sum()
+    p, o = hiplib.op_nms_detections(np.zeros((0, 4), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32), 0.45)
+    assert p.shape == (0, 3) and o.shape == (0,)
+    with pytest.raises(hiplib.YoloError):
+        hiplib.op_nms_detections(np.zeros((5000, 4), np.float32), np.zeros((5000, 2), np.float32), np.ones(5000, np.float32), 0.45)
