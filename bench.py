@@ -116,7 +116,7 @@ def main():
         except Exception:      # noqa: BLE001
             loaded = False
     if not loaded:
-        eng.autotune(B, 5)
+        eng.autotune(B, int(os.environ.get("BENCH_TUNE_ITERS", "5")))
         if rank == 0:
             out_dir = os.path.join(ROOT, "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
             json.dump({"num_cfgs": hip.op_conv_num_cfgs(), "cfgs": [int(v) for v in eng.get_tile_configs()]},
