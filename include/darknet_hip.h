@@ -7,8 +7,8 @@
  *
  * Differences, all visible to a caller that looks: `network_predict*` return the DECODED rows
  * [rows][5 + classes] = (cx, cy, w, h, objectness, class probabilities) of all heads instead of the raw activations of
- * the last layer; do_nms_* leave the array order unchanged (the reference qsorts it); [region] heads are not served by
- * get_network_boxes (yolo heads only); precision is bf16 unless DARKNET_HIP_DTYPE=fp32 is set in the environment. */
+ * the last layer; do_nms_* leave the array order unchanged (the reference qsorts it); [region] heads are served in their
+ * softmax form (no tree / map, no mask coefficients); precision is bf16 unless DARKNET_HIP_DTYPE=fp32 is set in the environment. */
 #ifndef DARKNET_HIP_H
 #define DARKNET_HIP_H
 #ifdef __cplusplus

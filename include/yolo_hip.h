@@ -126,6 +126,9 @@ int yolo_input_size(const yolo_ctx *ctx, int *height, int *width, int *channels)
 int yolo_num_rows(const yolo_ctx *ctx);      /* candidates per image: 10647 @416 v3, 845 v2 */
 int yolo_num_attrs(const yolo_ctx *ctx);     /* 5 + classes */
 int yolo_num_layers(const yolo_ctx *ctx);
+/* detection head number `head` (0-based, cfg order): kind 0 = [yolo], 1 = [region]; grid side; anchors per cell; first row of
+ * this head in the decoded tensor (rows are cell-major, anchor inner).  YOLO_ERR_INVALID past the last head. */
+int yolo_head_geometry(const yolo_ctx *ctx, int head, int *kind, int *grid, int *anchors, int *row_offset);
 double yolo_conv_flops(const yolo_ctx *ctx); /* 2*k*k*Cin*Cout*Ho*Wo summed (DN/convolutional_layer.c:325), per image */
 double yolo_conv_bytes(const yolo_ctx *ctx, int n); /* algorithmic HBM bytes of the conv stack for n images */
 

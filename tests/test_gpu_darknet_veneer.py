@@ -142,3 +142,47 @@ def test_network_predict_planar_input(pair):
     im = IMAGE(size, size, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
     b = np.ctypeslib.as_array(ven.network_predict_image(vnet, im), shape=(rows, 85)).copy()
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)                 # the letterbox of an S x S image is the identity
+
+
+def test_region_head_boxes_match_libdarknet(tmp_path, hiplib):
+    """A [region] topology (yolov2-tiny-voc: maxpool stack, softmax head, 4-int .weights header): every box of
+    get_network_boxes -- darknet reports all w*h*n of them, anchor-major, objectness / probabilities gated by thresh."""
+    if not DR.available():
+        pytest.skip("oracle/_ref/libdarknet_ref.so not built")
+    os.environ["DARKNET_HIP_DTYPE"] = "fp32"
+    size = 160
+    txt = IO.with_input_size(IO.cfg_text("yolov2-tiny-voc"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 23, obj_bias=0.0)
+    cfg = str(tmp_path / "net.cfg"); wf = str(tmp_path / "net.weights")
+    open(cfg, "w").write(txt); IO.write_weights_file(wf, flat, 0, 1)
+    ref = _bind(DR.lib())
+    ven = _bind(C.CDLL(os.path.join(ROOT, "yolo_tensorflow_amd", "libdarknet_hip.so")))
+    with DR._Quiet():
+        rnet = ref.load_network(cfg.encode(), wf.encode(), 0)
+        ref.set_batch_network(rnet, 1)
+    vnet = ven.load_network(cfg.encode(), wf.encode(), 0)
+    assert vnet
+    w, h = 210, 130
+    img = np.ascontiguousarray(np.random.default_rng(4).random((3, h, w), dtype=np.float32))
+    im = IMAGE(w, h, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+    ref.network_predict_image(rnet, im); assert bool(ven.network_predict_image(vnet, im))
+    nr, nv = C.c_int(0), C.c_int(0)
+    dr = ref.get_network_boxes(rnet, w, h, 0.0, .5, None, 1, C.byref(nr))
+    dv = ven.get_network_boxes(vnet, w, h, 0.0, .5, None, 1, C.byref(nv))
+    g = size // 32
+    assert nr.value == nv.value == g * g * 5
+    br, orr, pr = _collect(dr, nr.value, 20); bv, ov, pv = _collect(dv, nv.value, 20)
+    np.testing.assert_allclose(bv, br, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(ov, orr, rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(pv, pr, rtol=2e-3, atol=2e-4)
+    ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
+    # with a threshold: gated objectness / probabilities (entries within 1e-3 of the threshold excluded from the comparison)
+    thr = 0.3
+    dr = ref.get_network_boxes(rnet, w, h, thr, .5, None, 1, C.byref(nr)); dv = ven.get_network_boxes(vnet, w, h, thr, .5, None, 1, C.byref(nv))
+    _, o2r, p2r = _collect(dr, nr.value, 20); _, o2v, p2v = _collect(dv, nv.value, 20)
+    clear_o = np.abs(orr - thr) > 1e-3
+    assert np.array_equal(o2v[clear_o] == 0, o2r[clear_o] == 0) and (o2r == 0).sum() > 0
+    clear_p = (np.abs(pr - thr) > 1e-3) & clear_o[:, None]
+    assert np.array_equal((p2v == 0)[clear_p], (p2r == 0)[clear_p])
+    ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
+    ven.free_network(vnet); ref.free_network(rnet)

@@ -74,26 +74,52 @@ float *network_predict_image(network *net, image im)
     return net->det.data();
 }
 
-// get_yolo_detections (DN/yolo_layer.c:316-343) over every yolo head in network order, then correct_yolo_boxes
-// (DN/yolo_layer.c:247-273).  The decoded rows already hold get_yolo_box's (x, y, w, h) relative to the network input.
+// get_yolo_detections (DN/yolo_layer.c:316-343) / get_region_detections (DN/region_layer.c:364-437, softmax heads
+// without a tree) over every head in network order, then correct_yolo_boxes / correct_region_boxes (identical
+// arithmetic, DN/yolo_layer.c:247-273, DN/region_layer.c:336-362).  The decoded rows already hold get_yolo_box's /
+// get_region_box's (x, y, w, h) relative to the network input.
 detection *get_network_boxes(network *net, int w, int h, float thresh, float hier, int *map, int relative, int *num)
 {
     (void)hier; (void)map;
     if (num) *num = 0;
     if (!net || !net->have) return nullptr;
     const int A = net->attrs, C = A - 5;
+    // pass 1: how many detections (a yolo head reports objectness > thresh, a region head every box)
+    struct Head { int kind, grid, na, off; };
+    std::vector<Head> heads;
+    for (int k = 0;; ++k) { Head hd; if (yolo_head_geometry(net->ctx, k, &hd.kind, &hd.grid, &hd.na, &hd.off) != YOLO_OK) break; heads.push_back(hd); }
     int count = 0;
-    for (int r = 0; r < net->rows; ++r) if (net->det[(size_t)r * A + 4] > thresh) ++count;
+    for (auto &hd : heads) {
+        const int rows = hd.grid * hd.grid * hd.na;
+        if (hd.kind == 1) count += rows;
+        else for (int r = 0; r < rows; ++r) if (net->det[(size_t)(hd.off + r) * A + 4] > thresh) ++count;
+    }
     detection *dets = (detection *)calloc(count > 0 ? count : 1, sizeof(detection));
     int k = 0;
-    for (int r = 0; r < net->rows; ++r) {
-        const float *p = &net->det[(size_t)r * A];
-        const float objectness = p[4];
-        if (!(objectness > thresh)) continue;
-        detection &d = dets[k++];
-        d.bbox = box{p[0], p[1], p[2], p[3]}; d.classes = C; d.objectness = objectness;
-        d.prob = (float *)calloc(C, sizeof(float));
-        for (int j = 0; j < C; ++j) { const float prob = objectness * p[5 + j]; d.prob[j] = prob > thresh ? prob : 0; }
+    for (auto &hd : heads) {
+        const int cells = hd.grid * hd.grid;
+        if (hd.kind == 1) {
+            // region: index = anchor * cells + cell (DN/region_layer.c:395); objectness and probabilities gated by thresh
+            for (int n = 0; n < hd.na; ++n)
+                for (int i = 0; i < cells; ++i) {
+                    const float *p = &net->det[(size_t)(hd.off + i * hd.na + n) * A];
+                    detection &d = dets[k++];
+                    const float scale = p[4];
+                    d.bbox = box{p[0], p[1], p[2], p[3]}; d.classes = C; d.objectness = scale > thresh ? scale : 0;
+                    d.prob = (float *)calloc(C, sizeof(float));
+                    if (d.objectness) for (int j = 0; j < C; ++j) { const float prob = scale * p[5 + j]; d.prob[j] = prob > thresh ? prob : 0; }
+                }
+        } else {
+            for (int r = 0; r < cells * hd.na; ++r) {
+                const float *p = &net->det[(size_t)(hd.off + r) * A];
+                const float objectness = p[4];
+                if (!(objectness > thresh)) continue;
+                detection &d = dets[k++];
+                d.bbox = box{p[0], p[1], p[2], p[3]}; d.classes = C; d.objectness = objectness;
+                d.prob = (float *)calloc(C, sizeof(float));
+                for (int j = 0; j < C; ++j) { const float prob = objectness * p[5 + j]; d.prob[j] = prob > thresh ? prob : 0; }
+            }
+        }
     }
     const int netw = net->w, neth = net->h;
     int new_w, new_h;

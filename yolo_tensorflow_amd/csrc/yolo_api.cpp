@@ -865,6 +865,21 @@ int yolo_input_size(const yolo_ctx *c, int *h, int *w, int *ch) { if (!c) return
 int yolo_num_rows(const yolo_ctx *c) { return c ? c->rows : YOLO_ERR_INVALID; }
 int yolo_num_attrs(const yolo_ctx *c) { return c ? c->attrs : YOLO_ERR_INVALID; }
 int yolo_num_layers(const yolo_ctx *c) { return c ? (int)c->layers.size() : YOLO_ERR_INVALID; }
+int yolo_head_geometry(const yolo_ctx *c, int head, int *kind, int *grid, int *anchors, int *row_offset)
+{
+    if (!c || head < 0) return YOLO_ERR_INVALID;
+    int k = 0;
+    for (auto &L : c->layers) {
+        if (L.type != L_YOLO && L.type != L_REGION) continue;
+        if (k++ != head) continue;
+        if (kind) *kind = L.type == L_REGION ? 1 : 0;
+        if (grid) *grid = L.H;
+        if (anchors) *anchors = L.na;
+        if (row_offset) *row_offset = L.row_off;
+        return YOLO_OK;
+    }
+    return YOLO_ERR_INVALID;             // no such head
+}
 double yolo_conv_flops(const yolo_ctx *c) { return c ? c->conv_flops : 0; }
 double yolo_conv_bytes(const yolo_ctx *c, int n)
 {

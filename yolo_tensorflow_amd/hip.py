@@ -24,7 +24,7 @@ BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4")
 
 EXPORTS = [
     "yolo_create", "yolo_destroy", "yolo_last_error", "yolo_load_darknet_weights", "yolo_set_weights",
-    "yolo_weights_count", "yolo_set_act_scales", "yolo_export", "yolo_create_from_file", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers",
+    "yolo_weights_count", "yolo_set_act_scales", "yolo_export", "yolo_create_from_file", "yolo_input_size", "yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_head_geometry",
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
@@ -63,10 +63,11 @@ def load_library():
     l.yolo_set_weights.argtypes = [P, FP, C.c_size_t]
     l.yolo_weights_count.argtypes = [P]; l.yolo_weights_count.restype = C.c_size_t
     l.yolo_set_act_scales.argtypes = [P, P, I]
+    l.yolo_head_geometry.argtypes = [P, I, P, P, P, P]
     l.yolo_export.argtypes = [P, C.c_char_p]
     l.yolo_create_from_file.argtypes = [C.c_char_p, I, I, P, I, C.c_char_p, C.c_size_t]; l.yolo_create_from_file.restype = P
     l.yolo_input_size.argtypes = [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]
-    for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_synchronize"):
+    for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_head_geometry", "yolo_synchronize"):
         getattr(l, n).argtypes = [P]
     l.yolo_conv_flops.argtypes = [P]; l.yolo_conv_flops.restype = D
     l.yolo_conv_bytes.argtypes = [P, I]; l.yolo_conv_bytes.restype = D
