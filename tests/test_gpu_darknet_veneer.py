@@ -186,3 +186,43 @@ def test_region_head_boxes_match_libdarknet(tmp_path, hiplib):
     assert np.array_equal((p2v == 0)[clear_p], (p2r == 0)[clear_p])
     ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
     ven.free_network(vnet); ref.free_network(rnet)
+
+
+def test_python_detect_matches_reference_binding(pair, tmp_path):
+    """`yolo_tensorflow_amd.darknet.detect` (same flow as D2T/darknet.py:125-142) against that flow run on the compiled
+    reference: same (class, prob, box) list."""
+    from yolo_tensorflow_amd import darknet as DK
+    ref, rnet, ven, vnet, size = pair
+    w, h = 190, 150
+    rgb = np.random.default_rng(8).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    names = ["c%d" % i for i in range(80)]
+    # the fixture's network, re-opened through the module's own loader
+    size_txt = IO.with_input_size(IO.cfg_text("yolov3-tiny"), size)
+    flat = IO.synth_weights(IO.parse_cfg(size_txt), 21, obj_bias=0.0)
+    cfg = str(tmp_path / "n.cfg"); wf = str(tmp_path / "n.weights")
+    open(cfg, "w").write(size_txt); IO.write_weights_file(wf, flat, 0, 2)
+    net = DK.load_net(cfg, wf, 0)
+    got = DK.detect(net, names, rgb, thresh=0.4, nms=0.45)
+    DK.free_net(net)
+    im = DK.array_to_image(rgb)
+    rim = IMAGE(im.w, im.h, im.c, im.data)
+    ref.network_predict_image(rnet, rim)
+    num = C.c_int(0)
+    dets = ref.get_network_boxes(rnet, w, h, 0.4, .5, None, 0, C.byref(num))
+    ref.do_nms_obj(dets, num.value, 80, 0.45)
+    want = []
+    for j in range(num.value):
+        for i in range(80):
+            if dets[j].prob[i] > 0:
+                b = dets[j].bbox
+                want.append((names[i], dets[j].prob[i], (b.x, b.y, b.w, b.h)))
+    want = sorted(want, key=lambda x: -x[1])
+    ref.free_detections(dets, num.value)
+    assert len(got) > 10 and abs(len(got) - len(want)) <= 2          # entries within float noise of the threshold may flip
+    hits = 0
+    for n_, p, bx in want:                                            # same class, same probability, same box
+        for n2, p2, bx2 in got:
+            if n2 == n_ and abs(p2 - p) < 3e-3 and np.allclose(bx2, bx, rtol=3e-3, atol=3e-3 * max(w, h)):
+                hits += 1
+                break
+    assert hits >= len(want) - 3

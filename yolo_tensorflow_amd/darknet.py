@@ -1,0 +1,101 @@
+"""Counterpart of the reference's `darknet.py` (D2T/darknet.py:20-142): the same ctypes declarations (BOX, DETECTION,
+IMAGE), the same names (`load_net`, `predict_image`, `get_network_boxes`, `do_nms_obj`, `do_nms_sort`, `free_detections`,
+`detect`), bound to `libdarknet_hip.so` (include/darknet_hip.h) instead of `./libdarknet.so`.
+
+Differences a caller sees: `load_image` (stb JPEG decoding, D2T/darknet.py:105) and `load_meta` (class-name files, :101)
+are host-side helpers outside the inference path -- `detect` takes the image as an array (RGB, HWC uint8 or float 0..1, or
+a ready IMAGE) and the class names as a list."""
+import ctypes as C
+import os
+import numpy as np
+from .hip import YoloError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdarknet_hip.so")
+
+
+class BOX(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float)]
+
+
+class DETECTION(C.Structure):
+    _fields_ = [("bbox", BOX), ("classes", C.c_int), ("prob", C.POINTER(C.c_float)), ("mask", C.POINTER(C.c_float)),
+                ("objectness", C.c_float), ("sort_class", C.c_int)]
+
+
+class IMAGE(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("c", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YoloError("libdarknet_hip.so is not built (make -C yolo_tensorflow_amd/csrc); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        l.network_width.argtypes = [C.c_void_p]; l.network_width.restype = C.c_int
+        l.network_height.argtypes = [C.c_void_p]; l.network_height.restype = C.c_int
+        l.network_predict.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; l.network_predict.restype = C.POINTER(C.c_float)
+        l.network_predict_image.argtypes = [C.c_void_p, IMAGE]; l.network_predict_image.restype = C.POINTER(C.c_float)
+        l.get_network_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+        l.get_network_boxes.restype = C.POINTER(DETECTION)
+        l.free_detections.argtypes = [C.POINTER(DETECTION), C.c_int]
+        l.load_network.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; l.load_network.restype = C.c_void_p
+        l.free_network.argtypes = [C.c_void_p]
+        l.do_nms_obj.argtypes = [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]
+        l.do_nms_sort.argtypes = [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]
+        _lib = l
+    return _lib
+
+
+def load_net(cfg, weights, clear=0):
+    net = _load().load_network(os.fsencode(cfg), os.fsencode(weights) if weights else None, clear)
+    if not net:
+        raise YoloError("load_network failed for %s / %s" % (cfg, weights))
+    return net
+
+
+def free_net(net):
+    _load().free_network(net)
+
+
+def array_to_image(arr):
+    """HWC RGB uint8 (0..255) or float (0..1) -> darknet IMAGE (planar float 0..1); keeps the buffer alive on the result."""
+    a = np.asarray(arr)
+    a = a.astype(np.float32) / np.float32(255) if a.dtype == np.uint8 else a.astype(np.float32)
+    chw = np.ascontiguousarray(a.transpose(2, 0, 1))
+    im = IMAGE(chw.shape[2], chw.shape[1], chw.shape[0], chw.ctypes.data_as(C.POINTER(C.c_float)))
+    im._keep = chw
+    return im
+
+
+def predict_image(net, im):
+    out = _load().network_predict_image(net, im)
+    if not out:
+        raise YoloError("network_predict_image failed")
+    return out
+
+
+def detect(net, names, image, thresh=.5, hier_thresh=.5, nms=.45):
+    """D2T/darknet.py:125-142 with `image` an array / IMAGE and `names` the class-name list (meta.names)."""
+    l = _load()
+    im = image if isinstance(image, IMAGE) else array_to_image(image)
+    num = C.c_int(0)
+    predict_image(net, im)
+    dets = l.get_network_boxes(net, im.w, im.h, thresh, hier_thresh, None, 0, C.byref(num))
+    n = num.value
+    classes = len(names)
+    if nms:
+        l.do_nms_obj(dets, n, classes, nms)
+    res = []
+    for j in range(n):
+        for i in range(classes):
+            if dets[j].prob[i] > 0:
+                b = dets[j].bbox
+                res.append((names[i], dets[j].prob[i], (b.x, b.y, b.w, b.h)))
+    res = sorted(res, key=lambda x: -x[1])
+    l.free_detections(dets, n)
+    return res
