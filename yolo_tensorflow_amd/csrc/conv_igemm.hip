@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         const unsigned long long s1 = stamp();
         if (LOAD && is_loader) stage(fill);
         const unsigned long long s2 = stamp();
+        __builtin_amdgcn_s_setprio(2);          // MFMA phase: win issue arbitration against the co-resident workgroup's DMA / epilogue phases
         // Fragment reads are software-pipelined PD MFMA groups ahead and PINNED there with sched_group_barrier: left
         // alone the scheduler hoists every ds_read of the (half) step above the first MFMA and waits lgkmcnt(0), so
         // the LDS pipe and the MFMA pipe take turns instead of overlapping (all four waves are in the same phase).
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (DIAG) {
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
             const unsigned long long s3 = stamp();
