@@ -48,7 +48,9 @@ constexpr int ST_INCHUNKS = (ST_INPIX + 63) / 64;            // 64-pixel LDS-DMA
 constexpr int ST_IN_BYTES = ST_INCHUNKS * 1024 + 16;         // + one 16-B slot of zeros (taps 9..11 of the K padding)
 constexpr int ST_O2PITCH = 32 * 2 + 16;                      // staged tail tile: 32 bf16 + pad
 constexpr int ST_OUT2_BYTES = ST_TH * ST_TW * ST_O2PITCH;    // 10240
-constexpr int ST_W2_BYTES = 32 * 64 * 2;                     // tail filters [32][64] bf16, kept in LDS (no registers left)
+constexpr int ST_W2PITCH = 64 * 2 + 16;                      // tail filter row pitch: 128 B rows would put all 16 lanes of a
+                                                             // fragment read on two banks (8-way conflict)
+constexpr int ST_W2_BYTES = 32 * ST_W2PITCH;                 // tail filters [32][64] bf16, kept in LDS (no registers left)
 constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
                                                              // would make hipcc wait vmcnt(0) and drain the input prefetch
 
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 const bf16x8 x = *(const bf16x8 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bf16x8 w = *(const bf16x8 *)(lw2 + ((i * 16 + l15) * 64 + (kk * 4 + lq) * 8) * 2);
+                    const bf16x8 w = *(const bf16x8 *)(lw2 + (i * 16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
                     acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc2[i], 0, 0, 0);
                 }
             }
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
     char *const inb0 = smem, *const inb1 = smem + ST_IN_BYTES;
     char *const l0 = smem + 2 * ST_IN_BYTES, *const lo = l0 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
     if (a.w2)                                                    // tail filters -> LDS, 16 B per thread (256 pieces)
-        if (tid < ST_W2_BYTES / 16) {
+        if (tid < 32 * 8) {
             const int row = tid >> 3, piece = tid & 7;
-            *(uint4 *)(lw2 + row * 128 + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
+            *(uint4 *)(lw2 + row * ST_W2PITCH + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
             if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
         }
     if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
