@@ -189,9 +189,9 @@ def test_region_head_boxes_match_libdarknet(tmp_path, hiplib):
 
 
 def test_python_detect_matches_reference_binding(pair, tmp_path):
-    """`yolo_tensorflow_amd.darknet.detect` (same flow as D2T/darknet.py:125-142) against that flow run on the compiled
+    """`yolo_tensorflow_amd.darknet_hip.detect` (same flow as D2T/darknet.py:125-142) against that flow run on the compiled
     reference: same (class, prob, box) list."""
-    from yolo_tensorflow_amd import darknet as DK
+    from yolo_tensorflow_amd import darknet_hip as DK
     ref, rnet, ven, vnet, size = pair
     w, h = 190, 150
     rgb = np.random.default_rng(8).integers(0, 256, (h, w, 3), dtype=np.uint8)

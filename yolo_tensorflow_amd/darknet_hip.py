@@ -1,4 +1,4 @@
-"""Counterpart of the reference's `darknet.py` (D2T/darknet.py:20-142): the same ctypes declarations (BOX, DETECTION,
+"""Counterpart of the reference's `darknet.py` (D2T/darknet.py:20-142), named darknet_hip to keep the two apart: the same ctypes declarations (BOX, DETECTION,
 IMAGE), the same names (`load_net`, `predict_image`, `get_network_boxes`, `do_nms_obj`, `do_nms_sort`, `free_detections`,
 `detect`), bound to `libdarknet_hip.so` (include/darknet_hip.h) instead of `./libdarknet.so`.
 
@@ -30,24 +30,31 @@ class IMAGE(C.Structure):
 _lib = None
 
 
+# prototype table: name -> (restype, argtypes); the layouts are those of include/darknet_hip.h
+_PROTOTYPES = {
+    "load_network": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int]),
+    "free_network": (None, [C.c_void_p]),
+    "network_width": (C.c_int, [C.c_void_p]),
+    "network_height": (C.c_int, [C.c_void_p]),
+    "network_predict": (C.POINTER(C.c_float), [C.c_void_p, C.POINTER(C.c_float)]),
+    "network_predict_image": (C.POINTER(C.c_float), [C.c_void_p, IMAGE]),
+    "get_network_boxes": (C.POINTER(DETECTION), [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    "free_detections": (None, [C.POINTER(DETECTION), C.c_int]),
+    "do_nms_obj": (None, [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]),
+    "do_nms_sort": (None, [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]),
+}
+
+
 def _load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise YoloError("libdarknet_hip.so is not built (make -C yolo_tensorflow_amd/csrc); there is no CPU fallback")
-        l = C.CDLL(LIB_PATH)
-        l.network_width.argtypes = [C.c_void_p]; l.network_width.restype = C.c_int
-        l.network_height.argtypes = [C.c_void_p]; l.network_height.restype = C.c_int
-        l.network_predict.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; l.network_predict.restype = C.POINTER(C.c_float)
-        l.network_predict_image.argtypes = [C.c_void_p, IMAGE]; l.network_predict_image.restype = C.POINTER(C.c_float)
-        l.get_network_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
-        l.get_network_boxes.restype = C.POINTER(DETECTION)
-        l.free_detections.argtypes = [C.POINTER(DETECTION), C.c_int]
-        l.load_network.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; l.load_network.restype = C.c_void_p
-        l.free_network.argtypes = [C.c_void_p]
-        l.do_nms_obj.argtypes = [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]
-        l.do_nms_sort.argtypes = [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]
-        _lib = l
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype; fn.argtypes = argtypes
+        _lib = handle
     return _lib
 
 
