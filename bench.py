@@ -158,13 +158,18 @@ def main():
 
     if rank == 0:
         total_ms, conv_ms = eng.time_forward(B, 10, conv=True)
-        traffic = None      # HBM bytes per forward of the conv launches, from the committed PMC passes (cannot be read in-process)
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if args.size == 416 and B == 32 and not fp8 and os.path.exists(tpath):
+        # HBM bytes per forward of the conv launches: PMC counters cannot be read in-process, so this is the committed
+        # rocprofv3 measurement (tools/profile_round.sh) -- printed only when it was taken on exactly this code and tile plan
+        # (source hash), null otherwise: a stale number is never reported
+        traffic = None
+        from yolo_tensorflow_amd import buildinfo
+        for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
             try:
-                traffic = json.load(open(tpath))["conv_hbm_bytes_per_forward"]
+                tj = json.load(open(tpath))
+                if loaded and tj.get("source_hash") == buildinfo.source_hash(args.size, B, args.dtype):
+                    traffic = tj["conv_hbm_bytes_per_forward"]; break
             except Exception:      # noqa: BLE001
-                traffic = None
+                pass
         flops = eng.conv_flops() * B
         achieved = flops / (conv_ms * 1e-3) / 1e12
         out = {

@@ -27,67 +27,87 @@ if st:
     shutil.copy(st[0], os.path.join(dst, "%s_bench_kernel_stats.csv" % R))
 
 
+def build_hash():
+    """sha1 over the kernel sources and the committed bf16 plan: bench.py prints `roofline.traffic` only when the PMC
+    passes were taken on exactly the code and plan it is running (a stale constant can never be printed)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from yolo_tensorflow_amd import buildinfo
+    return buildinfo.source_hash(416, 32, "bf16")
+
+
 def counters(sub):
-    """{counter: {kernel: [values per dispatch in order]}} plus per-kernel durations of the same dispatches"""
+    """rows of one PMC pass in dispatch order: [(dispatch_id, kernel, {counter: value}, duration_ns)]; also copies the
+    raw CSV next to the summaries (they are 70-300 KB)"""
     f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
-    out = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(dict)
     if not f:
-        return out, dur
+        return []
+    shutil.copy(f[0], os.path.join(dst, "%s_%s_counter_collection.csv" % (R, sub)))
+    rows = {}
     for r in csv.DictReader(open(f[0])):
         try:
-            out[r["Counter_Name"]][r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-            dur[r["Kernel_Name"]][int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            d = int(r["Dispatch_Id"])
+            e = rows.setdefault(d, [d, r["Kernel_Name"], {}, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+            e[2][r["Counter_Name"]] = e[2].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         except (ValueError, KeyError, TypeError):
             pass
-    return out, dur
+    return [tuple(rows[d]) for d in sorted(rows)]
 
 
-def last_forward(per_kernel, n_forwards):
-    """sum over the dispatches of the LAST forward: each kernel's last (count / n_forwards) dispatches"""
-    tot = 0.0; detail = {}
-    for k, v in per_kernel.items():
-        if not (k.startswith("void conv_") or k.startswith("conv_")):
+def is_conv(k):
+    return k.startswith("void conv_") or k.startswith("conv_")
+
+
+def last_forward(rows):
+    """the dispatches of the LAST forward: everything from the last k_preprocess dispatch on (tools/prof_forward.py runs
+    one default-plan forward and then ITERS tuned ones; each forward starts with exactly one k_preprocess launch)"""
+    starts = [i for i, r in enumerate(rows) if "k_preprocess" in r[1]]
+    return rows[starts[-1]:] if starts else rows
+
+
+def per_kernel(rows, counter):
+    out = collections.OrderedDict()
+    for _, k, c, ns in rows:
+        if not is_conv(k) or counter not in c:
             continue
-        v = sorted(v); per = max(1, len(v) // n_forwards)
-        s = sum(x for _, x in v[-per:])
-        detail[k] = {"sum": s, "launches": per}; tot += s
-    return tot, detail
+        e = out.setdefault(k, {"sum": 0.0, "launches": 0, "ns": 0})
+        e["sum"] += c[counter]; e["launches"] += 1; e["ns"] += ns
+    return out
 
 
-NF = 3        # prof_forward.py: 1 planning forward + ITERS=2
-fetch, _ = counters("pmc_FETCH_SIZE"); write, _ = counters("pmc_WRITE_SIZE")
+fetch = last_forward(counters("pmc_FETCH_SIZE")); write = last_forward(counters("pmc_WRITE_SIZE"))
 if fetch and write:
-    f_tot, f_det = last_forward(fetch["FETCH_SIZE"], NF); w_tot, w_det = last_forward(write["WRITE_SIZE"], NF)
+    f_det = per_kernel(fetch, "FETCH_SIZE"); w_det = per_kernel(write, "WRITE_SIZE")
+    f_tot = sum(v["sum"] for v in f_det.values()); w_tot = sum(v["sum"] for v in w_det.values())
     json.dump({
-        "workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward",
-        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_forward.py (last forward); KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md",
+        "workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; forwards segmented at the k_preprocess dispatch; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md",
+        "source_hash": build_hash(),
+        "conv_launches": sum(v["launches"] for v in f_det.values()),
         "conv_fetch_size_kib_raw": f_tot, "conv_write_size_kib": w_tot,
         "conv_hbm_bytes_per_forward": int((2 * f_tot + w_tot) * 1024),
         "per_kernel_kib": {k: {"fetch_raw": f_det[k]["sum"], "write": w_det.get(k, {}).get("sum"), "launches": f_det[k]["launches"]} for k in f_det},
     }, open(os.path.join(dst, "%s_hbm_traffic.json" % R), "w"), indent=1)
 
-mf, dur = counters("pmc_SQ_VALU_MFMA_BUSY_CYCLES")
+mf = last_forward(counters("pmc_SQ_VALU_MFMA_BUSY_CYCLES"))
 if mf:
     rows = {}
-    for k in mf["SQ_VALU_MFMA_BUSY_CYCLES"]:
-        if "conv_" not in k:
-            continue
-        n = max(1, len(mf["SQ_VALU_MFMA_BUSY_CYCLES"][k]) // NF)
-        def tail(c):
-            return sum(x for _, x in sorted(mf[c][k])[-n:]) if k in mf[c] else None
-        ids = [d for d, _ in sorted(mf["SQ_VALU_MFMA_BUSY_CYCLES"][k])[-n:]]
-        ns = sum(dur[k][d] for d in ids)
-        busy, gui, cu = tail("SQ_VALU_MFMA_BUSY_CYCLES"), tail("GRBM_GUI_ACTIVE"), tail("SQ_BUSY_CU_CYCLES")
-        rows[k] = {"launches": n, "ns": ns, "mfma_busy_cycles": busy, "grbm_gui_active": gui, "sq_busy_cu_cycles": cu,
-                   # GRBM_GUI_ACTIVE is summed over 8 XCDs; MFMA busy is summed over 256 CUs x 4 SIMDs
-                   "mfma_util": (busy / 1024.0) / (gui / 8.0) if busy and gui else None,
-                   # GRBM-derived clock reads high on dispatches shorter than ~0.3 ms (guide, DVFS note), so also
-                   # state utilisation against wall time at the 2.4 GHz peak clock: this one x 2.5 PF = TFLOP/s
-                   "mfma_util_wall_2p4ghz": (busy / 1024.0) / (ns * 2.4) if busy and ns else None,
-                   "eff_clock_ghz": (gui / 8.0) / ns if gui and ns else None}
-    tb = sum(r["mfma_busy_cycles"] or 0 for r in rows.values()); tg = sum(r["grbm_gui_active"] or 0 for r in rows.values())
-    json.dump({"workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward",
-               "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE over tools/prof_forward.py (last forward); util = busy/(256 CUs*4 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs)",
+    for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CU_CYCLES"):
+        for k, v in per_kernel(mf, name).items():
+            e = rows.setdefault(k, {"launches": v["launches"], "ns": v["ns"]})
+            e[name] = v["sum"]
+    for k, e in rows.items():
+        busy, gui, ns = e.get("SQ_VALU_MFMA_BUSY_CYCLES"), e.get("GRBM_GUI_ACTIVE"), e["ns"]
+        # GRBM_GUI_ACTIVE is summed over 8 XCDs; MFMA busy is summed over 256 CUs x 4 SIMDs
+        e["mfma_util"] = (busy / 1024.0) / (gui / 8.0) if busy and gui else None
+        # GRBM-derived clock reads high on dispatches shorter than ~0.3 ms (guide, DVFS note), so also state utilisation
+        # against wall time at the 2.4 GHz peak clock: this one x 2.5 PF = TFLOP/s
+        e["mfma_util_wall_2p4ghz"] = (busy / 1024.0) / (ns * 2.4) if busy and ns else None
+        e["eff_clock_ghz"] = (gui / 8.0) / ns if gui and ns else None
+    tb = sum(r.get("SQ_VALU_MFMA_BUSY_CYCLES") or 0 for r in rows.values()); tg = sum(r.get("GRBM_GUI_ACTIVE") or 0 for r in rows.values())
+    json.dump({"workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
+               "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; forwards segmented at the k_preprocess dispatch; util = busy/(256 CUs*4 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs)",
+               "source_hash": build_hash(),
+               "conv_launches": sum(r["launches"] for r in rows.values()),
                "all_conv_mfma_util": (tb / 1024.0) / (tg / 8.0) if tg else None,
                "all_conv_mfma_util_wall_2p4ghz": (tb / 1024.0) / (sum(r["ns"] for r in rows.values()) * 2.4), "per_kernel": rows},
               open(os.path.join(dst, "%s_mfma_util.json" % R), "w"), indent=1)

@@ -24,6 +24,22 @@
 //     s_waitcnt vmcnt + one raw s_barrier per K-step keep them in flight across the barrier.
 #include "kernels.h"
 #include <cstdio>
+#include <mutex>
+#include <set>
+#include <utility>
+
+hipError_t conv_opt_in_lds(const void *kernel, size_t lds_bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -678,8 +694,7 @@ static hipError_t launch_conv_diag_t(const ConvArgs &a, hipStream_t s)
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
-    static bool done = false;
-    if (!done) { hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; done = true; }
+    { hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>, lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
@@ -850,13 +865,8 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL>();
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * (WP * WC + NL));   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
-        static bool done = false;      // per instantiation
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            done = true;
-        }
+        hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>, lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>), grid, block, lds, s, a);
     return hipGetLastError();

@@ -393,19 +393,17 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
 
 bool conv_halo_ok(const HaloArgs &a)
 {
+    // 32-bit buffer offsets below 0x80000000 (the out-of-range sentinel): input and shortcut windows must stay under 2 GiB
+    const double px = (double)a.N * a.H * a.W;
+    if (px * a.in_stride * 2.0 >= 2147483648.0 || (a.res && px * a.res_stride * 2.0 >= 2147483648.0)) return false;
     return a.Cin == 32 && a.Cout == 64 && a.Kpad >= 288 && (a.in_stride % 8) == 0 && a.in_stride >= 32 && (a.out_stride % 8) == 0 &&
            a.out_stride >= 64 && (!a.res || ((a.res_stride % 8) == 0 && a.res_stride >= 64));
 }
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s)
 {
     if (!conv_halo_ok(a)) return hipErrorInvalidValue;
-    static bool done = false;
     const size_t lds = (size_t)2 * HL_IN_BYTES + HL_RES_BYTES + ST_OUT_BYTES;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv_halo_c32_c64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    { hipError_t e = conv_opt_in_lds((const void *)conv_halo_c32_c64, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.W + ST_TW - 1) / ST_TW) * ((a.H + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;
     hipLaunchKernelGGL(conv_halo_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
@@ -414,6 +412,7 @@ hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s)
 
 bool conv_stem_ok(const StemArgs &a)
 {
+    if ((double)a.N * a.H * a.W * a.in_stride * 2.0 >= 2147483648.0) return false;       // 32-bit buffer offsets, see conv_halo_ok
     return a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&
            a.Ho == (a.H + 2 - 3) / 2 + 1 && a.Wo == (a.W + 2 - 3) / 2 + 1 &&
            (!a.w2 || (a.C2 == 32 && a.Kpad2 >= 64 && a.out2 && (a.out2_stride % 8) == 0 && a.out2_stride >= 32));
@@ -422,13 +421,8 @@ bool conv_stem_ok(const StemArgs &a)
 hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
-    static bool done = false;
     const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv_stem_c32_c64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    { hipError_t e = conv_opt_in_lds((const void *)conv_stem_c32_c64, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
     hipLaunchKernelGGL(conv_stem_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);

@@ -67,6 +67,8 @@ inline void conv_finalize(ConvArgs &a)
     magic((uint32_t)a.Wo, a.wo_mul, a.wo_shift);
 }
 
+// opt a kernel in to more than 64 KiB of dynamic LDS, once per (device, kernel) -- the attribute is per device
+hipError_t conv_opt_in_lds(const void *kernel, size_t lds_bytes);
 // bf16 MFMA implicit-GEMM conv.  cfg in [0, conv_num_cfgs()); returns hipError.
 #define CONV_CFG_DIRECT 1000          // first-layer direct kernel (Cin padded 3 -> 8), outside the tile table
 bool conv_c8_direct_ok(const ConvArgs &a);

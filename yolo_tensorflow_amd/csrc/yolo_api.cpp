@@ -272,7 +272,8 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         }
     }
     // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
-    if (c->dtype == YOLO_BF16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM")) {
+    // (the stem and halo kernels address their input with 32-bit buffer offsets: the whole-batch window must stay under 2 GiB)
+    if (c->dtype == YOLO_BF16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
         const Layer &A = c->layers[0], &B = c->layers[1];
         if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
             A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1) {
@@ -478,8 +479,8 @@ int run_layer(yolo_ctx *c, int i, int n)
             HaloArgs h; memset(&h, 0, sizeof h);
             h.in = a.in; h.in_stride = a.in_stride; h.w = a.wt; h.b = a.bias; h.Kpad = a.Kpad; h.Cin = L.cin; h.Cout = L.filters; h.act = L.act;
             h.res = a.res; h.res_stride = a.res_stride; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = L.H; h.W = L.W;
-            HIPCK(c, launch_conv_halo(h, s));
-            break;
+            if (conv_halo_ok(h)) { HIPCK(c, launch_conv_halo(h, s)); break; }
+            // window over 2 GiB (very large batches): the tiled kernel below checks its own window
         }
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
@@ -561,7 +562,12 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
     if (nms_mode < 0 || nms_mode > 3 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
     size_t need = (size_t)n * max_out;
     if ((int)need > c->boxes_cap) {
+        // a captured detect graph holds the old pointer (memset, NMS writes, D2D copy): it must not be replayed
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->gstate > 0) c->gstate = 0;
+        HIPCK(c, hipStreamSynchronize(c->stream));
         if (c->d_boxes) HIPCK(c, hipFree(c->d_boxes));
+        c->d_boxes = nullptr; c->boxes_cap = 0;
         HIPCK(c, hipMalloc(&c->d_boxes, need * sizeof(yolo_box))); c->boxes_cap = (int)need;
     }
     PostArgs p; memset(&p, 0, sizeof p);
@@ -594,7 +600,7 @@ TView make_view(void *p, int n, int h, int w, int c, int stride, int dt) { TView
 // fp8: `in_scale` (per input channel, or null = 1) is folded into the filters first, then every output channel c is
 // scaled so that its largest |w| maps to 448: code = e4m3(w * in_scale / osc[c]), osc[c] = max|w * in_scale| / 448.
 void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
-               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc)
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics = YOLO_SEM_TF)
 {
     const int n = L.filters, k = L.size, cin = L.cin;
     bias.assign(L.cout_pad, 0.f); osc.assign(L.cout_pad, 1.f);
@@ -602,7 +608,9 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int
     if (L.bn) {
         const float *beta = bn_or_bias, *gamma = beta + n, *mean = gamma + n, *var = mean + n;
         for (int o = 0; o < n; ++o) {
-            float s = gamma[o] / sqrtf(var[o] + 1e-5f);           // TF epsilon inside the sqrt (V3/yolo_v3.py:9)
+            // TF: epsilon inside the sqrt (V3/yolo_v3.py:9).  darknet semantics follow the reference's CPU normalize
+            // (DN/blas.c:154: (x - mean) / (sqrt(var) + .000001f)), the code oracle/_ref is compiled from
+            float s = semantics == YOLO_SEM_DARKNET ? gamma[o] / (sqrtf(var[o]) + 1e-6f) : gamma[o] / sqrtf(var[o] + 1e-5f);
             scale[o] = s; bias[o] = beta[o] - mean[o] * s;
         }
     } else {
@@ -740,7 +748,7 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
             channel_scales(c, L.in[0], in_sc);
             if ((int)in_sc.size() != L.cin) return fail(c, YOLO_ERR_STATE, "internal: scale vector of %zu for %d channels", in_sc.size(), L.cin);
         }
-        pack_conv(L, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc);
+        pack_conv(L, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics);
         HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));

@@ -67,7 +67,7 @@ def load_library():
     l.yolo_export.argtypes = [P, C.c_char_p]
     l.yolo_create_from_file.argtypes = [C.c_char_p, I, I, P, I, C.c_char_p, C.c_size_t]; l.yolo_create_from_file.restype = P
     l.yolo_input_size.argtypes = [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]
-    for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_head_geometry", "yolo_synchronize"):
+    for n in ("yolo_num_rows", "yolo_num_attrs", "yolo_num_layers", "yolo_synchronize"):
         getattr(l, n).argtypes = [P]
     l.yolo_conv_flops.argtypes = [P]; l.yolo_conv_flops.restype = D
     l.yolo_conv_bytes.argtypes = [P, I]; l.yolo_conv_bytes.restype = D
@@ -141,6 +141,7 @@ class Engine:
         self.num_layers = self.lib.yolo_num_layers(self.ctx)
         self.max_batch = max_batch
         self.dtype = dtype
+        self._own_stream = not stream
 
     @classmethod
     def from_file(cls, path, max_batch=1, device=0, keep_layers=False, stream=None):
@@ -157,6 +158,7 @@ class Engine:
         self.size = h.value
         self.rows = self.lib.yolo_num_rows(self.ctx); self.attrs = self.lib.yolo_num_attrs(self.ctx)
         self.num_layers = self.lib.yolo_num_layers(self.ctx); self.max_batch = max_batch; self.dtype = None
+        self._own_stream = not stream
         return self
 
     def export(self, path):
@@ -165,6 +167,19 @@ class Engine:
     def _check(self, rc, what):
         if rc != 0:
             raise YoloError("%s failed (%d): %s" % (what, rc, self.lib.yolo_last_error(self.ctx).decode()))
+
+    def _order_after_producer(self, *tensors):
+        """Stream ordering for device tensors.  An engine created with stream=None runs on a stream of its own, which
+        nothing orders against the torch stream that produced `tensors`: wait (on the host) for that stream first.  The
+        engine's own device outputs are valid after `synchronize()`.  With an explicit stream (e.g.
+        torch.cuda.current_stream().cuda_stream, what bench.py passes) everything is stream-ordered and nothing is waited for."""
+        if not self._own_stream:
+            return
+        for t in tensors:
+            if hasattr(t, "is_cuda") and t.is_cuda:
+                import torch
+                torch.cuda.current_stream(t.device).synchronize()
+                return
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -198,6 +213,7 @@ class Engine:
         """images: uint8 or float32 [n,S,S,3] (numpy, torch host/device tensor, or raw device pointer with
         n and fmt given).  Returns the decoded tensor [n, rows, attrs] (numpy) unless out/want_detections say otherwise."""
         p, loc = _ptr(images)
+        self._order_after_producer(images, out)
         if n is None:
             n = int(images.shape[0])
         if fmt is None:
@@ -225,6 +241,7 @@ class Engine:
         """-> list of structured arrays (BOX_DTYPE) per image, or writes into the given device buffers."""
         if boxes_out is not None:
             bp, bloc = _ptr(boxes_out); cp, _ = _ptr(counts_out)
+            self._order_after_producer(boxes_out, counts_out)
             self._check(self.lib.yolo_postprocess(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode, bp, cp, bloc), "yolo_postprocess")
             return None
         boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)
@@ -242,6 +259,7 @@ class Engine:
         p, loc = _ptr(images); bp, bl = _ptr(boxes_out); cp, cl = _ptr(counts_out)
         if loc != DEVICE or bl != DEVICE or cl != DEVICE:
             raise YoloError("detect_graph needs device-resident buffers")
+        self._order_after_producer(images, boxes_out, counts_out)
         fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
         self._check(self.lib.yolo_detect_graph(self.ctx, p, int(images.shape[0]), fmt, scale, score_thr, iou_thr, max_out,
                                                nms_mode, select_mode, bp, cp), "yolo_detect_graph")
