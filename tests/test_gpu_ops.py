@@ -59,10 +59,50 @@ def test_conv_bf16_every_tile_config_agrees(hiplib, shape):
     k, s, h, cin, cout = shape
     rng = np.random.default_rng(7)
     x, w, b, _, ref = _conv_case(rng, k, s, h, cin, cout, n=3)
-    outs = [hiplib.op_conv2d(x, w, b, stride=s, act=1, tile_cfg=c) for c in range(hiplib.op_conv_num_cfgs())]
+    outs = []
+    for c in range(hiplib.op_conv_num_cfgs()):
+        try:
+            outs.append(hiplib.op_conv2d(x, w, b, stride=s, act=1, tile_cfg=c))
+        except hiplib.YoloError as e:            # the halo-staged forms only take 3x3 / stride 1 / multiples of 13
+            assert "not applicable" in str(e)
+    assert len(outs) >= 36
     _assert_bf16_close(outs[0], ref)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])       # same K order in every tiling -> bit-identical
+
+
+HALO_CFGS = (36, 37, 38, 39, 40, 41, 42)
+
+
+@pytest.mark.parametrize("case", [(2, 13, 512, 1024, False), (2, 26, 256, 512, True), (1, 52, 128, 256, True), (1, 104, 64, 128, True),
+                                  (3, 13, 64, 96, False), (1, 26, 192, 200, True)],
+                         ids=lambda c: "n%d_h%d_%dto%d_res%d" % c)
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp8"])
+def test_conv_halo_staged_form(hiplib, case, dtype_name):
+    """The halo-staged 3x3 form (13x13 pixel block per workgroup, input halo staged once per channel chunk, taps as LDS
+    offsets) at the real YOLOv3-416 stage shapes, un-shrunk: vs the oracle (bf16) and bit-identical to the tiled form
+    (bf16 and fp8), with and without the fused shortcut, ragged channel counts included."""
+    n, h, cin, cout, residual = case
+    dtype = hiplib.BF16 if dtype_name == "bf16" else hiplib.FP8
+    if dtype == hiplib.FP8 and cin % 128:
+        pytest.skip("fp8 halo form needs whole 128-channel chunks")
+    rng = np.random.default_rng(n * 1000 + h + cin)
+    x = R.to_bf16(rng.standard_normal((n, h, h, cin)).astype(np.float32))
+    w = R.to_bf16((rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32))
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = R.to_bf16(rng.standard_normal((n, h, h, cout)).astype(np.float32)) if residual else None
+    tiled = hiplib.op_conv2d(x, w, b, act=1, residual=res, dtype=dtype, tile_cfg=16)
+    if dtype == hiplib.BF16:
+        ref = R.leaky_relu(R.conv2d_nhwc(x, w, 1) + b)
+        if residual:
+            _assert_bf16_close(tiled, R.to_bf16(ref) + res, scale=np.abs(ref) + np.abs(res))
+        else:
+            _assert_bf16_close(tiled, ref)
+    for cfg in HALO_CFGS:
+        got = hiplib.op_conv2d(x, w, b, act=1, residual=res, dtype=dtype, tile_cfg=cfg)
+        assert np.array_equal(got, tiled), "halo cfg %d differs from the tiled form" % cfg
+    with pytest.raises(hiplib.YoloError, match="not applicable"):
+        hiplib.op_conv2d(x[:, :12, :12], w, b, act=1, dtype=dtype, tile_cfg=36)
 
 
 def test_conv_bf16_residual_and_linear(hiplib):

@@ -1,0 +1,47 @@
+"""The RCCL exchange of the detect path on a real GPU: `nccl` backend (RCCL on ROCm), device tensors, the same
+`dist.gather_flat_records` call bench.py makes for N > 1.  World size 1 runs in this process on any box; the 2-rank variant
+needs two GPUs and is launched by `python -m torch.distributed.run --nproc-per-node 2 tools/rccl_check.py` (a pytest process
+that has initialised the GPU must not spawn/exec children on this pool).  Named zz so that it runs after the other GPU tests:
+it creates and destroys the default process group."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+from yolo_tensorflow_amd import darknet_io as IO, dist as ydist
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_gather_of_device_records_world1(hiplib):
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        pytest.fail("torch does not see the GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rccl_check
+    port = 29700 + os.getpid() % 1000
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rccl_check.run_check(rank=0, world=1, local_rank=0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_force_dist_path(hiplib, capsys, monkeypatch):
+    """bench.py's own N > 1 code path (process group, all_gather_into_tensor of the flat record buffer inside the timed loop)
+    at world size 1: BENCH_FORCE_DIST=1, in process."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("torch does not see the GPU")
+    monkeypatch.setenv("BENCH_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_PORT", str(30700 + os.getpid() % 1000))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["achieved"] > 0

@@ -12,7 +12,9 @@ plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tens
 if os.path.exists(plan) and os.environ.get("TUNE", "0") != "1":
     eng.set_tile_configs(json.load(open(plan))["cfgs"])
 else:
-    eng.autotune(B, 3)
+    eng.autotune(B, int(os.environ.get("TUNE_ITERS", "3")))
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out"); os.makedirs(out, exist_ok=True)
+    json.dump({"num_cfgs": hip.op_conv_num_cfgs(), "cfgs": [int(v) for v in eng.get_tile_configs()]}, open(os.path.join(out, "yolov3_%d_b%d_%s.json" % (size, B, DT)), "w"))
 cfgs = eng.get_tile_configs()
 ms = eng.time_layers(B, 20)
 shapes = IO.layer_shapes(secs)                  # (type, H, W, C_out, C_in)

@@ -1,0 +1,62 @@
+"""RCCL exchange check on real GPUs: every rank runs the detect path on its shard of a global batch (device-resident images,
+box records written in place by the library), then ONE all_gather_into_tensor of the flat record buffers
+(yolo_tensorflow_amd/dist.py, the call bench.py makes); every rank must end up with exactly the records a single engine
+produces for the whole batch.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/rccl_check.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def run_check(rank, world, local_rank, n_local=4, size=160, max_out=10):
+    import torch
+    from yolo_tensorflow_amd import hip, darknet_io as IO, dist as ydist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    txt = IO.with_input_size(IO.cfg_text("yolov3-tiny"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=1, obj_bias=1.0)
+    all_img = np.random.default_rng(7).integers(0, 256, (n_local * world, size, size, 3), dtype=np.uint8)
+    lo, hi = ydist.shard_bounds(n_local * world, world, rank)
+    stream = torch.cuda.current_stream(dev)
+    eng = hip.Engine(txt, max_batch=n_local * world, device=local_rank, stream=stream.cuda_stream)
+    eng.set_weights(flat)
+    # reference: the whole global batch on this rank's engine, host round trip
+    eng.forward(all_img, want_detections=False)
+    want = eng.postprocess(n_local * world, score_thr=0.3, iou_thr=0.5, max_out=max_out)
+    assert sum(len(w) for w in want) > 0
+    # sharded: device images in, records written in place, one collective
+    images = torch.from_numpy(all_img[lo:hi]).to(dev)
+    rec, boxes, counts = ydist.alloc_flat_records(n_local, max_out, dev)
+    for _ in range(3):                     # eager, capture, replay
+        eng.detect_graph(images, boxes, counts, score_thr=0.3, iou_thr=0.5, max_out=max_out)
+        rec_all = ydist.gather_flat_records(rec)
+    torch.cuda.synchronize(dev)
+    gb, gc = ydist.split_flat_records(rec_all, n_local, max_out)
+    gb = gb.cpu().numpy().view(hip.BOX_DTYPE).reshape(n_local * world, max_out); gc = gc.cpu().numpy()
+    for i in range(n_local * world):
+        assert gc[i] == len(want[i]) and np.array_equal(gb[i, :gc[i]], want[i]), "rank %d: image %d differs after the all-gather" % (rank, i)
+    # the ragged-shard form (padded blocks) on device tensors too
+    buf = torch.from_numpy(ydist.pack_records(gb[lo:hi], gc[lo:hi].astype(np.int32), max_out)).to(dev)
+    full = ydist.all_gather_detections(buf, n_local * world).cpu().numpy()
+    dets = ydist.unpack_records(full, hip.BOX_DTYPE, max_out)
+    for i in range(n_local * world):
+        assert np.array_equal(dets[i], want[i])
+    eng.close()
+    return True
+
+
+if __name__ == "__main__":
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lr = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lr))
+    run_check(rank, world, lr)
+    dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print("rccl_check ok: world %d" % world)

@@ -1,0 +1,45 @@
+// Halo-staged instantiations of the implicit-GEMM conv kernel (conv_igemm_kernel.h, HALO = true): 3x3 / stride 1 / pad 1 layers
+// whose spatial size is a multiple of 13 -- every residual-block 3x3 conv of a 416x416 darknet-53 (104, 52, 26, 13).
+// Replaces the same reference chain as conv_igemm.hip (DN/convolutional_layer.c:445-485; slim.conv2d V3/yolo_v3.py:47-60).
+#include "conv_igemm_kernel.h"
+
+bool conv_halo13_ok(const ConvArgs &a)
+{
+    const int row = a.in_dt == DT_FP8 ? 128 : 64;                  // channels of one 128-byte chunk
+    if (a.in_dt != DT_BF16 && a.in_dt != DT_FP8) return false;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.H % HALO_B || a.W % HALO_B || a.Cin_pad % row || a.kchunk != row || a.Kpad != 9 * a.Cin_pad) return false;
+    if (a.out_dt == DT_F32) return false;
+    // 32-bit buffer offsets below the out-of-range sentinel
+    return (double)a.N * a.H * a.W * a.in_stride * dt_size(a.in_dt) < 2147483648.0;
+}
+
+template <int WC, int TC, int NL, int EB, bool FREE = false>
+static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
+{
+    constexpr int WP = 1, TP = 11, NS = 2, BK = 64, BC = WC * TC * 16;
+    const long blocks = (long)a.N * (a.H / HALO_B) * (a.W / HALO_B);
+    const long tiles = blocks * ((a.Cout + BC - 1) / BC);
+    constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL, true>();
+    static_assert(lds <= 160 * 1024, "halo form: LDS");
+    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
+{
+    if (!conv_halo13_ok(a)) return hipErrorInvalidValue;
+    const bool f8 = a.in_dt == DT_FP8;
+    switch (cfg) {
+    case 36: return f8 ? launch_h<8, 2, 0, 1>(a, s) : launch_h<8, 2, 0, 2>(a, s);
+    case 37: return f8 ? launch_h<8, 2, 4, 1>(a, s) : launch_h<8, 2, 4, 2>(a, s);
+    case 38: return f8 ? launch_h<4, 2, 4, 1>(a, s) : launch_h<4, 2, 4, 2>(a, s);
+    case 39: return f8 ? launch_h<4, 2, 0, 1>(a, s) : launch_h<4, 2, 0, 2>(a, s);
+    case 40: return f8 ? launch_h<8, 2, 0, 1, true>(a, s) : launch_h<8, 2, 0, 2, true>(a, s);
+    case 41: return f8 ? launch_h<8, 1, 0, 1, true>(a, s) : launch_h<8, 1, 0, 2, true>(a, s);
+    case 42: return f8 ? launch_h<4, 2, 0, 1, true>(a, s) : launch_h<4, 2, 0, 2, true>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}

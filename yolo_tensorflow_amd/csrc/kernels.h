@@ -77,6 +77,10 @@ const char *conv_cfg_name(int cfg);
 // rough preference used when no autotune ran
 int conv_pick_cfg(const ConvArgs &a);
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
+// halo-staged 3x3 / stride 1 form (conv_halo13.hip): bf16 or fp8 operands, spatial size a multiple of 13, whole 128-byte channel chunks
+bool conv_halo13_ok(const ConvArgs &a);
+bool conv_cfg_is_halo(int cfg);
+hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
 bool conv_cfg_tail_ok(int cfg, int cout);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);

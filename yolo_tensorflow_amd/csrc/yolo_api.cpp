@@ -485,11 +485,13 @@ int run_layer(yolo_ctx *c, int i, int n)
         if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
+            if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
             if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_fp8(a, cfg, s));
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
+            if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);
             if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
@@ -1177,7 +1179,8 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int i = 0; i < NL; ++i) {
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
-                const bool ok = conv_cfg_tail_ok(cfg, L.filters);
+                bool ok = conv_cfg_tail_ok(cfg, L.filters);
+                if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo13_ok(a); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
             if (!any) continue;
@@ -1225,6 +1228,10 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
         if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters)))
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
+        if (tail && conv_cfg_is_halo(v)) {
+            ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
+            if (!conv_halo13_ok(a)) return fail(c, YOLO_ERR_INVALID, "layer %zu: the halo-staged tile config %d does not apply to this layer, so it cannot carry the fused 1x1 tail", i, v);
+        }
         c->layers[i].tile_cfg = v; c->layers[i].tail_on = tail;
     }
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0;
@@ -1273,6 +1280,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, dt); a.act = act; a.zeros = d_z;
     conv_finalize(a);
+    if (conv_cfg_is_halo(tile_cfg) && (f32 || !conv_halo13_ok(a))) { g_op_err = "conv2d: tile config not applicable to this shape (halo-staged form: 3x3, stride 1, size a multiple of 13, whole channel chunks)"; return YOLO_ERR_UNSUPPORTED; }
     hipError_t e;
     if (dt != DT_F32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build, printed to stderr
