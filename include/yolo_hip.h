@@ -151,6 +151,18 @@ int yolo_forward_image_u8(yolo_ctx *ctx, const uint8_t *image, int h, int w, int
 int yolo_forward_letterbox_chw(yolo_ctx *ctx, const float *image_chw, int w, int h, int loc,
                                float *detections_out, int out_loc);
 
+/* darknet's get_network_boxes on the device (DN/network.c:536-567 = num_detections + fill_network_boxes ->
+ * get_yolo_detections DN/yolo_layer.c:316-343 / get_region_detections DN/region_layer.c:364-437 (softmax heads, no tree),
+ * then correct_yolo_boxes DN/yolo_layer.c:247-273) over image 0 of the last forward: boxes above `thresh`, compacted in
+ * darknet's order, un-letterboxed for a w x h source image.  records: host [cap][5 + classes] = x, y, w, h, objectness,
+ * prob[classes]; *count = number of detections (may exceed cap; cap = 0 / records = NULL: count only = num_detections). */
+int yolo_darknet_boxes(yolo_ctx *ctx, int w, int h, float thresh, int relative, float *records, int cap, int *count);
+/* What darknet's network_predict returns (DN/network.c:497-508, net->output): the LAST layer's output of image 0 in darknet's
+ * own layout -- for a [yolo] / [region] layer the planar [anchors * (5 + classes)][grid * grid] tensor with that layer's
+ * activations applied (DN/yolo_layer.c:143-152, DN/region_layer.c:160-186).  host buffer of yolo_last_layer_size() floats. */
+size_t yolo_last_layer_size(const yolo_ctx *ctx);
+int yolo_last_layer_output(yolo_ctx *ctx, float *out, size_t out_floats);
+
 /* Threshold + NMS on the resident decoded tensor of the last forward (rows S, N1/N3).
  * boxes_out: [n * max_out] caller-owned, counts_out: [n]; both at out_loc.
  * Replaces get_network_boxes + do_nms_* (DN/network.c:562, DN/box.c:21-89) and the TF tail
@@ -209,6 +221,9 @@ int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const fl
                    int img_size, int decode, int region, float *out, int device);
 /* threshold + NMS over det [n,rows,attrs] fp32.  nms_mode bits 8..19 / 20..31 carry image height / width for
  * YOLO_NMS_PER_CLASS (V2 pixel boxes); select_mode bit 8 set = rows already hold corners (x0,y0,x1,y1). */
+/* darknet letterbox_image (embed = 1, DN/image.c:960-981) / resize_image (embed = 0, DN/image.c:1347-1389) of a planar
+ * float image [3][ih][iw] into a planar w x h image, on the device.  Host buffers. */
+int yolo_op_letterbox(const float *image_chw, int iw, int ih, int w, int h, int embed, float *out_chw, int device);
 /* darknet's do_nms_sort (by_objectness = 0) / do_nms_obj (1), DN/box.c:21-89, on caller arrays (host): boxes [n] (cx,cy,w,h),
  * prob [n][classes], objectness [n]; suppressed entries are zeroed IN PLACE (prob[j][k], or objectness[j] and all of
  * prob[j]); detections whose objectness is 0 do not take part.  n <= 4096.  Array order is left unchanged (the

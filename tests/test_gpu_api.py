@@ -162,3 +162,30 @@ def test_export_artifact_round_trip(hiplib, tmp_path, dtype_name):
             hiplib.Engine.from_file(bad)
     with pytest.raises(hiplib.YoloError):
         hiplib.Engine.from_file(str(tmp_path / "missing.yolohip"))
+
+
+def test_detect_skips_the_decoded_tensor_but_not_the_boxes(hiplib):
+    """yolo_detect / yolo_detect_graph go from the head convs to box records without materialising the [n, rows, 5+C] decoded
+    tensor (the decode writes scores, labels and the four box numbers only): same records as forward + postprocess, bit for bit,
+    for the TF and the darknet NMS flavours; a flavour that needs the tensor afterwards is refused with a code, not served stale."""
+    import ctypes as C
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 160)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=2)
+    img = np.random.default_rng(6).integers(0, 256, (3, 160, 160, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=3)
+    eng.set_weights(flat)
+    for mode in (hiplib.NMS_TF, hiplib.NMS_DARKNET):
+        eng.forward(img, want_detections=False)
+        want = eng.postprocess(3, score_thr=0.3, iou_thr=0.45, max_out=30, nms_mode=mode)
+        boxes = np.zeros((3, 30), dtype=hiplib.BOX_DTYPE); counts = np.zeros(3, np.int32)
+        rc = eng.lib.yolo_detect(eng.ctx, img.ctypes.data, 3, hiplib.IMG_U8, hiplib.HOST, 1.0 / 255.0, 0.3, 0.45, 30, mode, hiplib.SELECT_GT,
+                                 boxes.ctypes.data, counts.ctypes.data, hiplib.HOST)
+        assert rc == 0
+        assert sum(len(w) for w in want) > 10
+        for b in range(3):
+            assert counts[b] == len(want[b]) and np.array_equal(boxes[b, :counts[b]], want[b])
+    with pytest.raises(hiplib.YoloError, match="without materialising"):
+        eng.postprocess(3, score_thr=0.3, nms_mode=hiplib.NMS_NUMPY_V3)
+    eng.forward(img, want_detections=False)
+    assert len(eng.postprocess(3, score_thr=0.3, nms_mode=hiplib.NMS_NUMPY_V3)) == 3
+    eng.close()

@@ -133,15 +133,100 @@ def test_do_nms_obj_matches_libdarknet(pair):
     ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
 
 
-def test_network_predict_planar_input(pair):
-    """network_predict on a planar image already at network size == network_predict_image of the same image."""
+def test_network_predict_returns_last_layer_output(pair):
+    """network_predict's return value is net->output (DN/network.c:497-508): the last [yolo] layer's planar output with its
+    logistic activations -- same floats as the compiled reference returns; and network_predict on a planar image already at
+    network size equals network_predict_image of it (the letterbox of an S x S image is the identity)."""
     ref, rnet, ven, vnet, size = pair
     img = np.ascontiguousarray(np.random.default_rng(1).random((3, size, size), dtype=np.float32))
-    rows = 3 * (5 * 5 + 10 * 10)
-    a = np.ctypeslib.as_array(ven.network_predict(vnet, img.ctypes.data_as(C.POINTER(C.c_float))), shape=(rows, 85)).copy()
+    g = size // 16                                                          # yolov3-tiny's last head: stride 16
+    n_out = 255 * g * g
+    pr = ref.network_predict(rnet, img.ctypes.data_as(C.POINTER(C.c_float)))
+    want = np.ctypeslib.as_array(pr, shape=(n_out,)).copy()
+    a = np.ctypeslib.as_array(ven.network_predict(vnet, img.ctypes.data_as(C.POINTER(C.c_float))), shape=(n_out,)).copy()
+    np.testing.assert_allclose(a, want, rtol=2e-3, atol=2e-4)
     im = IMAGE(size, size, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
-    b = np.ctypeslib.as_array(ven.network_predict_image(vnet, im), shape=(rows, 85)).copy()
-    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)                 # the letterbox of an S x S image is the identity
+    b = np.ctypeslib.as_array(ven.network_predict_image(vnet, im), shape=(n_out,)).copy()
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_make_network_boxes_and_batch(pair):
+    """make_network_boxes (DN/network.c:526): as many zeroed detections as get_network_boxes reports; set_batch_network(2):
+    two planar images in, the first image's boxes out (DN/network.c:339, get_yolo_detections reads batch element 0)."""
+    ref, rnet, ven, vnet, size = pair
+    ven.make_network_boxes.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_int)]; ven.make_network_boxes.restype = C.POINTER(DR.DETECTION)
+    ven.set_batch_network.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(31)
+    two = np.ascontiguousarray(rng.random((2, 3, size, size), dtype=np.float32))
+    assert bool(ven.network_predict(vnet, two[0].ctypes.data_as(C.POINTER(C.c_float))))
+    n0, n1 = C.c_int(0), C.c_int(0)
+    d0 = ven.get_network_boxes(vnet, size, size, 0.4, .5, None, 1, C.byref(n0))
+    d1 = ven.make_network_boxes(vnet, 0.4, C.byref(n1))
+    assert n1.value == n0.value > 5 and d1[0].classes == 80 and d1[0].prob[3] == 0.0 and d1[n1.value - 1].objectness == 0.0
+    b0, o0, p0 = _collect(d0, n0.value, 80)
+    ven.free_detections(d1, n1.value); ven.free_detections(d0, n0.value)
+    ven.set_batch_network(vnet, 2)
+    assert bool(ven.network_predict(vnet, two.ctypes.data_as(C.POINTER(C.c_float))))
+    n2 = C.c_int(0)
+    d2 = ven.get_network_boxes(vnet, size, size, 0.4, .5, None, 1, C.byref(n2))
+    b2, o2, p2 = _collect(d2, n2.value, 80)
+    assert n2.value == n0.value and np.array_equal(b2, b0) and np.array_equal(o2, o0) and np.array_equal(p2, p0)
+    ven.free_detections(d2, n2.value)
+    ven.set_batch_network(vnet, 1)
+
+
+def test_image_helpers_match_libdarknet(pair, tmp_path):
+    """letterbox_image (device), rgbgr_image, load_image_color (PPM, with and without the resize) and get_metadata against the
+    compiled reference's functions of the same names (load_image_color: against the reference's resize_image of the same pixels,
+    its stb decoder is outside the path); free_ptrs releases what get_metadata allocated."""
+    ref, rnet, ven, vnet, size = pair
+
+    class METADATA(C.Structure):
+        _fields_ = [("classes", C.c_int), ("names", C.POINTER(C.c_char_p))]
+    for lib in (ref, ven):
+        lib.letterbox_image.argtypes = [IMAGE, C.c_int, C.c_int]; lib.letterbox_image.restype = IMAGE
+        lib.rgbgr_image.argtypes = [IMAGE]; lib.free_image.argtypes = [IMAGE]
+        lib.get_metadata.argtypes = [C.c_char_p]; lib.get_metadata.restype = METADATA
+        lib.free_ptrs.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    ref.resize_image.argtypes = [IMAGE, C.c_int, C.c_int]; ref.resize_image.restype = IMAGE
+    ven.load_image_color.argtypes = [C.c_char_p, C.c_int, C.c_int]; ven.load_image_color.restype = IMAGE
+    rng = np.random.default_rng(77)
+    for (w, h, W, H) in ((200, 120, 160, 160), (96, 250, 208, 128), (64, 64, 64, 64)):
+        img = np.ascontiguousarray(rng.random((3, h, w), dtype=np.float32))
+        im = IMAGE(w, h, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+        a = ref.letterbox_image(im, W, H); b = ven.letterbox_image(im, W, H)
+        assert (b.w, b.h, b.c) == (a.w, a.h, a.c) == (W, H, 3)
+        x = np.ctypeslib.as_array(a.data, shape=(3, H, W)).copy(); y = np.ctypeslib.as_array(b.data, shape=(3, H, W)).copy()
+        np.testing.assert_allclose(y, x, rtol=0, atol=2e-6)
+        ref.rgbgr_image(a); ven.rgbgr_image(b)
+        assert np.array_equal(np.ctypeslib.as_array(b.data, shape=(3, H, W)), y[::-1])
+        np.testing.assert_allclose(np.ctypeslib.as_array(b.data, shape=(3, H, W)), np.ctypeslib.as_array(a.data, shape=(3, H, W)), rtol=0, atol=2e-6)
+        ref.free_image(a); ven.free_image(b)
+    # PPM in, planar float out; with a target size: darknet's resize_image
+    rgb = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    ppm = str(tmp_path / "a.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n# a comment\n70 50\n255\n" + rgb.tobytes())
+    im = ven.load_image_color(ppm.encode(), 0, 0)
+    assert (im.w, im.h, im.c) == (70, 50, 3)
+    planar = np.ctypeslib.as_array(im.data, shape=(3, 50, 70)).copy()
+    assert np.array_equal(planar, (rgb.transpose(2, 0, 1).astype(np.float32) / np.float64(255.)).astype(np.float32))
+    im2 = ven.load_image_color(ppm.encode(), 96, 64)
+    rim = ref.resize_image(im, 96, 64)
+    np.testing.assert_allclose(np.ctypeslib.as_array(im2.data, shape=(3, 64, 96)), np.ctypeslib.as_array(rim.data, shape=(3, 64, 96)), rtol=0, atol=2e-6)
+    ven.free_image(im); ven.free_image(im2); ref.free_image(rim)
+    bad = ven.load_image_color(str(tmp_path / "missing.ppm").encode(), 0, 0)
+    assert not bad.data
+    # .data file + names list
+    names = ["person", "bicycle", "traffic light", "dog"]
+    (tmp_path / "n.names").write_text("\n".join(names) + "\n")
+    (tmp_path / "n.data").write_text("classes= 4\ntrain  = /nowhere\nnames = %s\nbackup = /nowhere\n" % (tmp_path / "n.names"))
+    with DR._Quiet():
+        mr = ref.get_metadata(str(tmp_path / "n.data").encode())
+    mv = ven.get_metadata(str(tmp_path / "n.data").encode())
+    assert mv.classes == mr.classes == 4
+    assert [mv.names[i] for i in range(4)] == [mr.names[i] for i in range(4)] == [n.encode() for n in names]
+    ven.free_ptrs(C.cast(mv.names, C.POINTER(C.c_void_p)), 4)
 
 
 def test_region_head_boxes_match_libdarknet(tmp_path, hiplib):
@@ -203,6 +288,17 @@ def test_python_detect_matches_reference_binding(pair, tmp_path):
     open(cfg, "w").write(size_txt); IO.write_weights_file(wf, flat, 0, 2)
     net = DK.load_net(cfg, wf, 0)
     got = DK.detect(net, names, rgb, thresh=0.4, nms=0.45)
+    # the reference's own calling convention: a file name and a METADATA (D2T/darknet.py:125-126, 162-164)
+    ppm = str(tmp_path / "img.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+    (tmp_path / "c.names").write_text("\n".join(names) + "\n")
+    (tmp_path / "c.data").write_text("classes=80\nnames=%s\n" % (tmp_path / "c.names"))
+    meta = DK.load_meta(str(tmp_path / "c.data"))
+    got_file = DK.detect(net, meta, ppm, thresh=0.4, nms=0.45)
+    assert len(got_file) == len(got)
+    for (n1, p1, b1), (n2, p2, b2) in zip(got_file, got):
+        assert n1.decode() == n2 and p1 == p2 and b1 == b2
     DK.free_net(net)
     im = DK.array_to_image(rgb)
     rim = IMAGE(im.w, im.h, im.c, im.data)

@@ -5,7 +5,8 @@ over all 32 images of the batch with the measured min IoU / max |dscore| printed
 Stated tolerances (boxes of every oracle candidate whose score clears the 0.5 threshold by more than the score bound, so that
 a legitimate flip across the threshold is not counted):
   bf16 (BASELINE config 3):  IoU >= 0.99,  |dscore| <= 1e-2      (SURVEY.md 8d asks 0.99 for bf16 storage)
-  fp8  (BASELINE config 5):  IoU >= 0.80,  |dscore| <= 0.15      calibrated power-of-two scales; e4m3 keeps 3 mantissa bits
+  fp8  (BASELINE config 5):  IoU >= FP8_IOU, |dscore| <= FP8_DSCORE over EVERY oracle candidate (no margin), calibrated
+                             power-of-two scales; e4m3 keeps 3 mantissa bits
 The fp32 device path is held to IoU >= 0.999 in test_gpu_network.py."""
 import glob
 import json
@@ -18,6 +19,7 @@ from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 
 pytestmark = pytest.mark.gpu
+FP8_IOU, FP8_DSCORE = 0.85, 0.03        # measured on MI355X (4910 candidates): min IoU 0.878, max |dscore| 0.021 -- DESIGN.md section 4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLANS = sorted(glob.glob(os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_*.json")))
 
@@ -153,8 +155,8 @@ def test_config5_fp8_416_b32_full_size(hiplib):
         ob, os_, oc = R.detect_v3_tf(det[b], 0.5, 0.5, 20)
         assert np.array_equal(res[b]["score"], os_) and np.array_equal(res[b]["cls"], oc)
     ref = oracle_detections(txt, flat, img, 416)
-    u = box_deviation(ref, det, 0.15)
-    print("fp8 416 b32, unit scales, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, lost %d" % (u[2], u[0], u[1], u[3]))
+    u = box_deviation(ref, det, 0.0)
+    print("fp8 416 b32, unit scales, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, below threshold %d" % (u[2], u[0], u[1], u[3]))
     eng.close()
     # calibrated scales from one image's fp32 per-layer maxima (oracle.fp8_calibrate_scales)
     osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
@@ -164,10 +166,11 @@ def test_config5_fp8_416_b32_full_size(hiplib):
     eng.set_weights(flat); eng.set_tile_configs(plan)
     detc = eng.forward(img)
     eng.close()
-    miou, mds, cnt, lost = box_deviation(ref, detc, 0.15)
-    print("fp8 416 b32, calibrated scales, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, lost %d" % (cnt, miou, mds, lost))
-    assert cnt > 50 and lost == 0
-    assert miou >= 0.80 and mds <= 0.15
+    # every oracle candidate (score > 0.5, no margin: a candidate close to the threshold may legitimately fall below it)
+    miou, mds, cnt, lost = box_deviation(ref, detc, 0.0)
+    print("fp8 416 b32, calibrated scales, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, below threshold %d" % (cnt, miou, mds, lost))
+    assert cnt > 1000
+    assert miou >= FP8_IOU and mds <= FP8_DSCORE
 
 
 def test_graph_survives_box_buffer_growth(hiplib):

@@ -104,3 +104,27 @@ def test_darknet_veneer_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(root, "yolo_tensorflow_amd", "libdarknet_hip.so"))
     for n in names:
         assert hasattr(lib, n), n
+
+
+# every symbol the reference's Python binding resolves from libdarknet.so when it is imported / when detect() runs
+# (D2T/darknet.py:49-115: `lib.X` and `X = lib.Y` lines)
+DARKNET_PY_SYMBOLS = ["network_width", "network_height", "network_predict", "cuda_set_device", "make_image", "get_network_boxes",
+                      "make_network_boxes", "free_detections", "free_ptrs", "reset_rnn", "load_network", "do_nms_obj", "do_nms_sort",
+                      "free_image", "letterbox_image", "get_metadata", "load_image_color", "rgbgr_image", "network_predict_image"]
+
+
+def test_darknet_veneer_exports_everything_darknet_py_binds():
+    import ctypes as C
+    import re
+    path = os.path.join(ROOT, "yolo_tensorflow_amd", "libdarknet_hip.so")
+    assert os.path.exists(path), "libdarknet_hip.so is not built"
+    lib = C.CDLL(path)
+    for name in DARKNET_PY_SYMBOLS:
+        assert hasattr(lib, name), "libdarknet_hip.so lacks %s" % name
+    hdr = open(os.path.join(ROOT, "include", "darknet_hip.h")).read()
+    for name in DARKNET_PY_SYMBOLS + ["free_network", "set_batch_network"]:
+        assert re.search(r"\b%s\(" % name, hdr), "include/darknet_hip.h does not declare %s" % name
+    ref = "/root/reference/Darknet2Tensorflow/darknet-master/darknet.py"
+    if os.path.exists(ref):                       # build container only: the list above is what that file binds
+        bound = set(re.findall(r"\blib\.(\w+)", open(ref).read()))
+        assert bound == set(DARKNET_PY_SYMBOLS), bound ^ set(DARKNET_PY_SYMBOLS)

@@ -384,3 +384,42 @@ hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *o
     WITH_DT(out_dt, hipLaunchKernelGGL(k_letterbox_chw<T>, grid_for((size_t)S * S), dim3(256), 0, s, img, iw, ih, S, new_w, new_h, (S - new_w) / 2, (S - new_h) / 2, (T *)out, out_stride));
     return hipGetLastError();
 }
+
+// ---- darknet letterbox_image (DN/image.c:960-981: resize_image to the aspect-preserving size, embedded in a 0.5-grey w x h
+//      canvas) and resize_image itself (DN/image.c:1347-1389; embed == 0: the image is stretched to w x h), planar float in,
+//      planar float out.  Same two-pass operation order as k_letterbox_chw above. ----
+__global__ void k_letterbox_planar(const float *img, int iw, int ih, int W, int H, int new_w, int new_h, int off_x, int off_y, float *out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    const int oy = p / W, ox = p - oy * W;
+    const int r = oy - off_y, c = ox - off_x;
+    float v[3] = {0.5f, 0.5f, 0.5f};
+    if ((unsigned)r < (unsigned)new_h && (unsigned)c < (unsigned)new_w) {
+        const float w_scale = (float)(iw - 1) / (float)(new_w - 1), h_scale = (float)(ih - 1) / (float)(new_h - 1);
+        const float sy = (float)r * h_scale; const int iy = (int)sy; const float dy = sy - (float)iy;
+        const bool last_c = c == new_w - 1 || iw == 1, last_r = r == new_h - 1 || ih == 1;
+        const float sx = (float)c * w_scale; const int ix = (int)sx; const float dx = sx - (float)ix;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float *pl = img + (size_t)k * iw * ih;
+            auto part = [&](int row) {
+                if (last_c) return pl[(size_t)row * iw + (iw - 1)];
+                return (1 - dx) * pl[(size_t)row * iw + ix] + dx * pl[(size_t)row * iw + ix + 1];
+            };
+            float val = (1 - dy) * part(iy);
+            if (!last_r) val = val + dy * part(iy + 1);
+            v[k] = val;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(size_t)k * W * H + p] = v[k];
+}
+hipError_t launch_letterbox_planar(const float *img, int iw, int ih, int w, int h, int embed, float *out, hipStream_t s)
+{
+    int new_w = w, new_h = h;
+    if (embed) { if (((float)w / iw) < ((float)h / ih)) { new_w = w; new_h = (ih * w) / iw; } else { new_h = h; new_w = (iw * h) / ih; } }
+    if (new_w < 1 || new_h < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_letterbox_planar, grid_for((size_t)w * h), dim3(256), 0, s, img, iw, ih, w, h, new_w, new_h, (w - new_w) / 2, (h - new_h) / 2, out);
+    return hipGetLastError();
+}

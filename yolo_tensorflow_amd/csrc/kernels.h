@@ -135,7 +135,8 @@ struct DecodeArgs {
     int img_size;
     int mode;                           // yolo_decode
     int region;                         // 1: softmax/region head
-    float *det; int rows_total; int row_off;   // det [n, rows_total, 5+classes]
+    float *det; int rows_total; int row_off;   // det [n, rows_total, 5+classes]; nullptr: the decoded tensor is not materialised ...
+    float *box4;                        // ... only (cx, cy, w, h) of every row, [n, rows_total, 4] (yolo heads, with scores/labels)
 };
 // scores/labels (nullable): per-row max_k(obj*cls_k) and its first argmax, written alongside the decode
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s);
@@ -143,6 +144,7 @@ hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStr
 struct PostArgs {
     const float *det; int n, rows, attrs;
     float score_thr, iou_thr; int max_out, nms_mode, select_mode;
+    const float *box4;                  // non-null: [n, rows, 4] (cx,cy,w,h) rows written by the lean decode; `det` is not read
     int scores_ready;                   // 1: scores/labels were produced by the decode kernel already
     int corners_in;                     // 1: det rows already hold (x0,y0,x1,y1) instead of (cx,cy,w,h)
     int img_h, img_w;                   // V2 numpy flavour only: pixel box scaling (V2/utils.py:32-43); 0 = off
@@ -155,4 +157,18 @@ struct PostArgs {
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);
 hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *out, int out_dt, int out_stride, hipStream_t s);
 hipError_t launch_nms_dets(const float4 *boxes, float *prob, float *objectness, int n, int classes, float thresh, int by_obj, hipStream_t s);
+// darknet get_network_boxes on the device (post_ops.hip): ordered compaction + letterbox correction of one image's decoded rows
+struct DnBoxesArgs {
+    const float *det; int attrs;          // decoded rows of ONE image [rows][attrs]
+    int nheads, kind[8], grid[8], na[8], off[8];   // per head: 0 yolo / 1 region, grid size, anchors, first row
+    float thresh; int w, h, netw, neth, relative;
+    float *rec;                           // [cap][attrs]: x, y, w, h, objectness, prob[classes]; nullptr = count only
+    int *src;                             // workspace [>= cap] (row index of every kept box)
+    int *count; int cap;
+};
+hipError_t launch_darknet_boxes(const DnBoxesArgs &a, hipStream_t s);
+// last head's raw output -> darknet's layer-output layout (planar, activations applied); image 0
+hipError_t launch_head_darknet_layout(const float *raw, int raw_stride, int cells, int na, int classes, int region, float *out, hipStream_t s);
+// darknet letterbox_image / resize_image on a planar float image -> planar float canvas w x h (DN/image.c:960-981)
+hipError_t launch_letterbox_planar(const float *img, int iw, int ih, int w, int h, int embed, float *out, hipStream_t s);
 hipError_t launch_boxes_to_corners(const float *in, float *out, size_t nrows, int attrs, hipStream_t s);

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_decode_yolo_cell(const DecodeArgs a, fl
         const int b = (int)(up / (unsigned)gg), cell = (int)(up - (unsigned)b * gg);
         const int cy = cell / a.g, cx = cell - cy * a.g;
         const size_t row0 = (size_t)b * a.rows_total + a.row_off + (size_t)cell * a.na;
-        float *dst = a.det + row0 * attrs;
+        float *dst = a.det ? a.det + row0 * attrs : nullptr;
+        float *dst4 = a.box4 ? a.box4 + row0 * 4 : nullptr;            // lean form: geometry only (the caller wants boxes, not the tensor)
         float x[R], v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) x[r] = xn[r];
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void k_decode_yolo_cell(const DecodeArgs a, fl
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 v[r] = spec_[r] ? vs : sigmoid_fast(x[r]);
-                if (ok_[r]) dst[lane + 64 * r] = v[r];
+                if (dst) { if (ok_[r]) dst[lane + 64 * r] = v[r]; }
+                else if (spec_[r]) dst4[an_[r] * 4 + k_[r]] = v[r];
             }
         } else {
 #pragma unroll
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(256) void k_decode_yolo_cell(const DecodeArgs a, fl
                 } else {
                     v[r] = sigmoid_fast(x[r]);
                 }
-                if (ok_[r]) dst[lane + 64 * r] = v[r];
+                if (dst) { if (ok_[r]) dst[lane + 64 * r] = v[r]; }
+                else if (spec_[r]) dst4[an_[r] * 4 + k_[r]] = v[r];
             }
         }
         if (!scores) continue;
@@ -258,6 +261,8 @@ __global__ void k_decode_region(const DecodeArgs a)
 
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s)
 {
+    // the lean form (no decoded tensor) exists in the cell-per-wave kernel only
+    if (!a.det && (a.region || !a.box4 || !scores || a.na * (5 + a.classes) > 256 || a.raw_stride < a.na * (5 + a.classes))) return hipErrorInvalidValue;
     if (a.region) {
         size_t total = (size_t)a.n * a.g * a.g * a.na;
         hipLaunchKernelGGL(k_decode_region, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, a);
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     // (4) gather candidates in sorted order
     for (int i = tid; i < M; i += NMS_THREADS) {
         int row = cand[(unsigned int)(keys[i] & (a.nms_mode == 3 ? 0x7fffu : 0xffffffffu))];
-        const float *p = a.det + ((size_t)img * a.rows + row) * a.attrs;
+        const float *p = a.box4 ? a.box4 + ((size_t)img * a.rows + row) * 4 : a.det + ((size_t)img * a.rows + row) * a.attrs;
         float4 b;
         if (a.nms_mode == 2 || a.corners_in) b = float4{p[0], p[1], p[2], p[3]};       // (cx,cy,w,h) for darknet; given corners
         else {
@@ -645,5 +650,114 @@ hipError_t launch_nms_dets(const float4 *boxes, float *prob, float *objectness, 
     if (n < 1) return hipSuccess;
     if (n > NMSD_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_nms_dets, dim3(by_obj ? 1 : classes), dim3(1024), 0, s, boxes, prob, objectness, n, classes, thresh, by_obj);
+    return hipGetLastError();
+}
+
+// ---- darknet's get_network_boxes on the device (DN/network.c:536-567): num_detections + fill_network_boxes over the decoded rows
+//      of one image.  [yolo] heads (get_yolo_detections, DN/yolo_layer.c:316-343): rows with objectness > thresh, in head / cell /
+//      anchor order, prob[j] = objectness * class_j gated by thresh.  [region] heads without a tree (get_region_detections,
+//      DN/region_layer.c:364-437): every box, anchor-major, objectness and probabilities gated by thresh.  Then
+//      correct_yolo_boxes / correct_region_boxes (DN/yolo_layer.c:247-273 = DN/region_layer.c:336-362: undo the letterbox).  The
+//      box arithmetic below restates those lines operation for operation (the reference mixes float and double there, and the
+//      veneer is compared with it to the last bits) -- this file is built with -ffp-contract=off.
+//      One workgroup: an ordered compaction of ~10^4 rows is latency-, not bandwidth-bound. ----
+__global__ __launch_bounds__(1024) void k_darknet_boxes(const DnBoxesArgs a)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int hd = 0; hd < a.nheads; ++hd) {
+        const int cells = a.grid[hd] * a.grid[hd], rows = cells * a.na[hd];
+        if (a.kind[hd] == 1) {
+            const int base = s_base;
+            for (int r = tid; r < rows; r += 1024) {
+                const int i = r / a.na[hd], n = r - i * a.na[hd];
+                const int pos = base + n * cells + i;              // index = n * w * h + i (DN/region_layer.c:395)
+                if (pos < a.cap) a.src[pos] = a.off[hd] + r;
+            }
+            __syncthreads();
+            if (tid == 0) s_base = base + rows;
+            __syncthreads();
+        } else {
+            for (int r0 = 0; r0 < rows; r0 += 1024) {
+                const int r = r0 + tid;
+                const bool keep = r < rows && a.det[(size_t)(a.off[hd] + r) * a.attrs + 4] > a.thresh;
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0) s_wave[wv] = __popcll(m);
+                __syncthreads();
+                int before = s_base, total = 0;
+                for (int k = 0; k < 16; ++k) { if (k < wv) before += s_wave[k]; total += s_wave[k]; }
+                if (keep) { const int pos = before + __popcll(m & ((1ull << lane) - 1ull)); if (pos < a.cap) a.src[pos] = a.off[hd] + r; }
+                __syncthreads();
+                if (tid == 0) s_base += total;
+                __syncthreads();
+            }
+        }
+    }
+    const int count = s_base;
+    if (tid == 0) *a.count = count;
+    if (!a.rec) return;
+    __threadfence_block();
+    const int n = count < a.cap ? count : a.cap;
+    const int netw = a.netw, neth = a.neth, w = a.w, h = a.h;
+    int new_w, new_h;
+    if (((float)netw / w) < ((float)neth / h)) { new_w = netw; new_h = (h * netw) / w; } else { new_h = neth; new_w = (w * neth) / h; }
+    // which head a row belongs to decides the gating
+    for (long idx = tid; idx < (long)n * a.attrs; idx += 1024) {
+        const int rec = (int)(idx / a.attrs), k = (int)(idx - (long)rec * a.attrs);
+        const int row = a.src[rec];
+        int kind = 0;
+        for (int hd = 0; hd < a.nheads; ++hd) if (row >= a.off[hd]) kind = a.kind[hd];
+        const float *p = a.det + (size_t)row * a.attrs;
+        const float obj_raw = p[4];
+        const float objectness = kind == 1 ? (obj_raw > a.thresh ? obj_raw : 0.f) : obj_raw;
+        float v;
+        if (k == 0) { v = (p[0] - (netw - new_w) / 2. / netw) / ((float)new_w / netw); if (!a.relative) v *= w; }
+        else if (k == 1) { v = (p[1] - (neth - new_h) / 2. / neth) / ((float)new_h / neth); if (!a.relative) v *= h; }
+        else if (k == 2) { v = p[2]; v *= (float)netw / new_w; if (!a.relative) v *= w; }
+        else if (k == 3) { v = p[3]; v *= (float)neth / new_h; if (!a.relative) v *= h; }
+        else if (k == 4) v = objectness;
+        else { const float prob = obj_raw * p[k]; v = (objectness != 0.f && prob > a.thresh) ? prob : 0.f; }
+        a.rec[idx] = v;
+    }
+}
+hipError_t launch_darknet_boxes(const DnBoxesArgs &a, hipStream_t s)
+{
+    if (a.nheads < 1 || a.nheads > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_darknet_boxes, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- the last layer's output in darknet's own layout, what `network_predict` returns (DN/network.c:497-508 -> net->output):
+//      a [yolo] layer's output is its input with the logistic applied to x, y, objectness and the class scores
+//      (DN/yolo_layer.c:143-152), a [region] layer's (softmax form) the logistic on x, y, objectness and a softmax over the classes
+//      (DN/region_layer.c:163-200), both planar [anchor * (5 + classes) + attr][cell].  logistic = 1./(1. + exp(-x)) evaluated in
+//      double like DN/activations.h:38. ----
+__global__ void k_head_darknet_layout(const float *raw, int raw_stride, int cells, int na, int classes, int region, float *out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= cells * na) return;
+    const int cell = r / na, n = r - cell * na, attrs = 5 + classes;
+    const float *p = raw + (size_t)cell * raw_stride + n * attrs;
+    float *o = out + (size_t)n * attrs * cells + cell;
+    auto lg = [](float x) { return (float)(1. / (1. + exp(-(double)x))); };
+    o[0] = lg(p[0]); o[(size_t)cells] = lg(p[1]); o[(size_t)2 * cells] = p[2]; o[(size_t)3 * cells] = p[3]; o[(size_t)4 * cells] = lg(p[4]);
+    if (!region) {
+        for (int k = 0; k < classes; ++k) o[(size_t)(5 + k) * cells] = lg(p[5 + k]);
+    } else {
+        // softmax (DN/blas.c:305-321, temperature 1): largest first, exp(x - largest), normalised by the running sum
+        float largest = -3.402823466e+38f;
+        for (int k = 0; k < classes; ++k) if (p[5 + k] > largest) largest = p[5 + k];
+        float sum = 0.f;
+        for (int k = 0; k < classes; ++k) { const float e = (float)exp((double)(p[5 + k] - largest)); sum += e; o[(size_t)(5 + k) * cells] = e; }
+        for (int k = 0; k < classes; ++k) o[(size_t)(5 + k) * cells] /= sum;
+    }
+}
+hipError_t launch_head_darknet_layout(const float *raw, int raw_stride, int cells, int na, int classes, int region, float *out, hipStream_t s)
+{
+    const int rows = cells * na;
+    hipLaunchKernelGGL(k_head_darknet_layout, dim3((rows + 255) / 256), dim3(256), 0, s, raw, raw_stride, cells, na, classes, region, out);
     return hipGetLastError();
 }

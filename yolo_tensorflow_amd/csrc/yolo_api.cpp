@@ -77,10 +77,14 @@ struct yolo_ctx {
     void *d_zeros = nullptr;
     void *d_stage = nullptr; size_t stage_bytes = 0;     // host->device image staging
     float *d_det = nullptr; int rows = 0, attrs = 0;
+    // lean detect path (yolo_detect*): the decode writes scores, labels and the four box numbers of every row, not the tensor
+    float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false;
     // postprocess workspace
     float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
     void *d_boxes = nullptr; int *d_counts = nullptr; int boxes_cap = 0;
+    // darknet-flavoured outputs (yolo_darknet_boxes / yolo_last_layer_output): records, row list, count, last layer's planar output
+    float *d_dn_rec = nullptr; int *d_dn_src = nullptr; int *d_dn_count = nullptr; float *d_dn_last = nullptr;
     // yolo_detect_graph state
     struct GKey { const void *img; int n, fmt; float scale, st, it; int mo, nm, sm; void *bo, *co; } gkey{};
     hipGraphExec_t gexec = nullptr; int gstate = 0;      // 0: next call eager, 1: next call captures, 2: replay, -1: capture unsupported
@@ -409,6 +413,12 @@ int allocate(yolo_ctx *c)
     HIPCK(c, hipMalloc(&c->d_stage, c->stage_bytes));
     size_t nr = (size_t)c->max_batch * c->rows;
     HIPCK(c, hipMalloc((void **)&c->d_det, nr * c->attrs * 4));
+    HIPCK(c, hipMalloc((void **)&c->d_box4, nr * 16));
+    c->lean_ok = true;                  // every head a [yolo] head the cell-per-wave decode serves
+    for (auto &L : c->layers) {
+        if (L.type == L_REGION) c->lean_ok = false;
+        if (L.type == L_YOLO && L.na * (5 + L.classes) > 256) c->lean_ok = false;
+    }
     c->rows_pow2 = 1; while (c->rows_pow2 < c->rows) c->rows_pow2 <<= 1;
     HIPCK(c, hipMalloc((void **)&c->d_scores, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_labels, nr * 4));
     HIPCK(c, hipMalloc((void **)&c->d_cand, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_keys, (size_t)c->max_batch * c->rows_pow2 * 8));
@@ -522,7 +532,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         const int stride = c->in_h / L.H;
         for (int k = 0; k < 2 * L.na; ++k)
             d.anchors[k] = L.type == L_YOLO ? (float)(1.0 * (double)L.anchors[k] / (double)stride) : L.anchors[k];
-        d.det = c->d_det; d.rows_total = c->rows; d.row_off = L.row_off;
+        d.det = c->lean ? nullptr : c->d_det; d.box4 = c->lean ? c->d_box4 : nullptr; d.rows_total = c->rows; d.row_off = L.row_off;
         HIPCK(c, launch_decode(d, c->d_scores, c->d_labels, s));
         break; }
     }
@@ -543,10 +553,11 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     return YOLO_OK;
 }
 
-int run_network(yolo_ctx *c, int n)
+int run_network(yolo_ctx *c, int n, bool lean = false)
 {
-    for (int i = 0; i < (int)c->layers.size(); ++i) { int r = run_layer(c, i, n); if (r) return r; }
-    c->last_n = n; c->scores_mode = 0;
+    c->lean = lean && c->lean_ok;
+    for (int i = 0; i < (int)c->layers.size(); ++i) { int r = run_layer(c, i, n); if (r) { c->lean = false; return r; } }
+    c->last_n = n; c->scores_mode = 0; c->det_valid = !c->lean;
     return YOLO_OK;
 }
 
@@ -573,7 +584,7 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
         HIPCK(c, hipMalloc(&c->d_boxes, need * sizeof(yolo_box))); c->boxes_cap = (int)need;
     }
     PostArgs p; memset(&p, 0, sizeof p);
-    p.det = det; p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_out;
+    p.det = det; p.box4 = (det == c->d_det && !c->det_valid) ? c->d_box4 : nullptr; p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_out;
     p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w; p.scores_ready = scores_ready;
     p.scores = c->d_scores; p.labels = c->d_labels; p.cand = c->d_cand; p.keys = c->d_keys; p.rows_pow2 = c->rows_pow2;
     p.sbox = c->d_sbox; p.slabel = c->d_slabel; p.sscore = c->d_sscore; p.boxes_out = c->d_boxes; p.counts_out = c->d_counts;
@@ -708,7 +719,8 @@ void yolo_destroy(yolo_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void *p : c->phys) if (p) hipFree(p);
     for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); }
-    void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts};
+    void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
+                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -905,16 +917,22 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
     return b;
 }
 
-int yolo_forward(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc)
+// lean: the caller goes straight on to threshold + NMS (yolo_detect*): the decoded tensor is not written, see yolo_ctx::lean
+static int forward_impl(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc, bool lean)
 {
     if (!c) return YOLO_ERR_INVALID;
     if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward before weights were loaded");
     if (fmt != YOLO_IMG_U8 && fmt != YOLO_IMG_F32 && fmt != YOLO_IMG_F32_CHW) return fail(c, YOLO_ERR_INVALID, "bad image format");
     HIPCK(c, hipSetDevice(c->device));
     int r = stage_in(c, images, n, fmt, loc, scale); if (r) return r;
-    r = run_network(c, n); if (r) return r;
+    r = run_network(c, n, lean && !det_out); if (r) return r;
     if (det_out) return copy_out(c, det_out, c->d_det, (size_t)n * c->rows * c->attrs * 4, out_loc);
     return YOLO_OK;
+}
+
+int yolo_forward(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc)
+{
+    return forward_impl(c, images, n, fmt, loc, scale, det_out, out_loc, false);
 }
 
 int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int loc, float *det_out, int out_loc)
@@ -962,6 +980,8 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
     if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "postprocess of %d images but the last forward ran %d", n, c->last_n);
     HIPCK(c, hipSetDevice(c->device));
     const int want = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
+    if (!c->det_valid && want != c->scores_mode)
+        return fail(c, YOLO_ERR_STATE, "the last forward ran through yolo_detect* without materialising the decoded tensor; this NMS flavour needs it (call yolo_forward)");
     const int ready = c->scores_mode == want;
     c->scores_mode = want;
     return post(c, c->d_det, n, c->rows, c->attrs, score_thr, iou_thr, max_out, nms_mode, select_mode,
@@ -971,7 +991,7 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
 int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float score_thr, float iou_thr,
                 int max_out, int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
 {
-    int r = yolo_forward(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE); if (r) return r;
+    int r = forward_impl(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3); if (r) return r;
     return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, out_loc);
 }
 
@@ -986,7 +1006,7 @@ int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float sca
         c->gkey = k; if (c->gstate >= 0) c->gstate = 0;
     }
     auto eager = [&]() -> int {
-        int r = yolo_forward(c, images, n, fmt, YOLO_DEVICE, scale, nullptr, YOLO_DEVICE); if (r) return r;
+        int r = forward_impl(c, images, n, fmt, YOLO_DEVICE, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3); if (r) return r;
         return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, YOLO_DEVICE);
     };
     if (c->gstate <= 0) { int r = eager(); if (r == YOLO_OK && c->gstate == 0) c->gstate = 1; return r; }
@@ -1004,6 +1024,64 @@ int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float sca
     }
     HIPCK(c, hipGraphLaunch(c->gexec, c->stream));
     c->last_n = n; c->scores_mode = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
+    return YOLO_OK;
+}
+
+// ---- darknet-flavoured views of the last forward (image 0), used by the veneer libdarknet_hip.so ----
+int yolo_darknet_boxes(yolo_ctx *c, int w, int h, float thresh, int relative, float *records, int cap, int *count)
+{
+    if (!c || !count) return YOLO_ERR_INVALID;
+    if (c->last_n < 1 || !c->det_valid) return fail(c, YOLO_ERR_STATE, "yolo_darknet_boxes needs a yolo_forward* pass first");
+    if (w < 1 || h < 1 || cap < 0 || (cap > 0 && !records)) return fail(c, YOLO_ERR_INVALID, "bad image size / capacity");
+    HIPCK(c, hipSetDevice(c->device));
+    if (!c->d_dn_rec) {
+        HIPCK(c, hipMalloc((void **)&c->d_dn_rec, (size_t)c->rows * c->attrs * 4));
+        HIPCK(c, hipMalloc((void **)&c->d_dn_src, (size_t)c->rows * 4));
+        HIPCK(c, hipMalloc((void **)&c->d_dn_count, 4));
+    }
+    DnBoxesArgs a; memset(&a, 0, sizeof a);
+    a.det = c->d_det; a.attrs = c->attrs;
+    for (auto &L : c->layers) {
+        if (L.type != L_YOLO && L.type != L_REGION) continue;
+        if (a.nheads == 8) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 8 heads");
+        a.kind[a.nheads] = L.type == L_REGION; a.grid[a.nheads] = L.H; a.na[a.nheads] = L.na; a.off[a.nheads] = L.row_off; ++a.nheads;
+    }
+    a.thresh = thresh; a.w = w; a.h = h; a.netw = c->in_w; a.neth = c->in_h; a.relative = relative;
+    a.cap = cap < c->rows ? cap : c->rows;
+    a.rec = a.cap > 0 ? c->d_dn_rec : nullptr; a.src = c->d_dn_src; a.count = c->d_dn_count;
+    HIPCK(c, launch_darknet_boxes(a, c->stream));
+    int n = 0;
+    HIPCK(c, hipMemcpyAsync(&n, c->d_dn_count, 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
+    *count = n;
+    const int got = n < a.cap ? n : a.cap;
+    if (got > 0) { HIPCK(c, hipMemcpyAsync(records, c->d_dn_rec, (size_t)got * c->attrs * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream)); }
+    return YOLO_OK;
+}
+
+size_t yolo_last_layer_size(const yolo_ctx *c)
+{
+    if (!c) return 0;
+    for (int i = (int)c->layers.size() - 1; i >= 0; --i) {
+        const Layer &L = c->layers[i];
+        if (L.type == L_YOLO || L.type == L_REGION) return (size_t)L.H * L.W * L.na * (5 + L.classes);
+    }
+    return 0;
+}
+
+int yolo_last_layer_output(yolo_ctx *c, float *out, size_t out_floats)
+{
+    if (!c || !out) return YOLO_ERR_INVALID;
+    if (c->last_n < 1) return fail(c, YOLO_ERR_STATE, "yolo_last_layer_output before a forward pass");
+    const int li = (int)c->layers.size() - 1;
+    if (li < 1 || (c->layers[li].type != L_YOLO && c->layers[li].type != L_REGION))
+        return fail(c, YOLO_ERR_UNSUPPORTED, "the last layer is not a detection head");
+    const Layer &L = c->layers[li]; const Layer &P = c->layers[li - 1];
+    const size_t need = yolo_last_layer_size(c);
+    if (out_floats < need) return fail(c, YOLO_ERR_INVALID, "output buffer too small (%zu < %zu floats)", out_floats, need);
+    HIPCK(c, hipSetDevice(c->device));
+    if (!c->d_dn_last) HIPCK(c, hipMalloc((void **)&c->d_dn_last, need * 4));
+    HIPCK(c, launch_head_darknet_layout((const float *)P.out.ptr, P.out.stride, L.H * L.W, L.na, L.classes, L.type == L_REGION, c->d_dn_last, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->d_dn_last, need * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
     return YOLO_OK;
 }
 
@@ -1042,6 +1120,7 @@ int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *con
     if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
     HIPCK(c, hipSetDevice(c->device));
     hipEvent_t e0, e1; HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    c->lean = false;
     if (total_ms) {
         HIPCK(c, hipEventRecord(e0, c->stream));
         for (int it = 0; it < iters; ++it) { int r = run_network(c, n); if (r) return r; }
@@ -1064,7 +1143,7 @@ int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *con
             float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); (pass == 0 ? all_ms : rest_ms) = ms / iters;
         }
         *conv_ms = all_ms - rest_ms;
-        c->last_n = n; c->scores_mode = 0;
+        c->last_n = n; c->scores_mode = 0; c->det_valid = true;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     return YOLO_OK;
@@ -1077,6 +1156,7 @@ int yolo_time_layers(yolo_ctx *c, int n, int iters, float *ms_out)
     if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
     HIPCK(c, hipSetDevice(c->device));
     const int NL = (int)c->layers.size();
+    c->lean = false; c->det_valid = true;
     std::vector<hipEvent_t> ev(NL + 1);
     for (auto &e : ev) HIPCK(c, hipEventCreate(&e));
     std::vector<double> acc(NL, 0.0);
@@ -1338,6 +1418,16 @@ int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float post_scale,
     if (S.rc) return S.rc;
     if (!S.ok(launch_resize_u8(d_i, h, w, s, d_o, 1, 3, 3, S.s, post_scale))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, (size_t)s * s * 3 * 4);
+}
+
+int yolo_op_letterbox(const float *image_chw, int iw, int ih, int w, int h, int embed, float *out_chw, int device)
+{
+    if (!image_chw || !out_chw || iw < 1 || ih < 1 || w < 1 || h < 1) { g_op_err = "letterbox: bad arguments"; return YOLO_ERR_INVALID; }
+    OpScope S(device); if (S.rc) { g_op_err = "letterbox: no HIP device"; return S.rc; }
+    float *d_i = (float *)S.upload(image_chw, (size_t)iw * ih * 3 * 4), *d_o = (float *)S.alloc((size_t)w * h * 3 * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_letterbox_planar(d_i, iw, ih, w, h, embed, d_o, S.s))) { g_op_err = S.err; return S.rc; }
+    return S.download(out_chw, d_o, (size_t)w * h * 3 * 4);
 }
 
 int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const float *anchors_wh, int img_size, int decode,

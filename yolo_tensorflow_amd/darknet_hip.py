@@ -1,10 +1,12 @@
-"""Counterpart of the reference's `darknet.py` (D2T/darknet.py:20-142), named darknet_hip to keep the two apart: the same ctypes declarations (BOX, DETECTION,
-IMAGE), the same names (`load_net`, `predict_image`, `get_network_boxes`, `do_nms_obj`, `do_nms_sort`, `free_detections`,
-`detect`), bound to `libdarknet_hip.so` (include/darknet_hip.h) instead of `./libdarknet.so`.
+"""Counterpart of the reference's `darknet.py` (D2T/darknet.py:20-142), named darknet_hip to keep the two apart: the same ctypes
+declarations (BOX, DETECTION, IMAGE, METADATA) and every name that file binds (`load_net`, `load_meta`, `load_image`,
+`predict_image`, `get_network_boxes`, `make_network_boxes`, `do_nms_obj`, `do_nms_sort`, `free_detections`, `free_ptrs`,
+`letterbox_image`, `rgbgr_image`, `set_gpu`, `reset_rnn`, `detect`), bound to `libdarknet_hip.so` (include/darknet_hip.h)
+instead of `./libdarknet.so`.
 
-Differences a caller sees: `load_image` (stb JPEG decoding, D2T/darknet.py:105) and `load_meta` (class-name files, :101)
-are host-side helpers outside the inference path -- `detect` takes the image as an array (RGB, HWC uint8 or float 0..1, or
-a ready IMAGE) and the class names as a list."""
+Differences a caller sees: `load_image` decodes binary PPM / PGM only (the reference's stb JPEG decoding, D2T/darknet.py:105,
+is outside the inference path), so `detect` also takes the image as an array (RGB, HWC uint8 or float 0..1) or a ready IMAGE, and
+the class names as a METADATA or a plain list."""
 import ctypes as C
 import os
 import numpy as np
@@ -27,6 +29,10 @@ class IMAGE(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("c", C.c_int), ("data", C.POINTER(C.c_float))]
 
 
+class METADATA(C.Structure):
+    _fields_ = [("classes", C.c_int), ("names", C.POINTER(C.c_char_p))]
+
+
 _lib = None
 
 
@@ -42,6 +48,17 @@ _PROTOTYPES = {
     "free_detections": (None, [C.POINTER(DETECTION), C.c_int]),
     "do_nms_obj": (None, [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]),
     "do_nms_sort": (None, [C.POINTER(DETECTION), C.c_int, C.c_int, C.c_float]),
+    "cuda_set_device": (None, [C.c_int]),
+    "make_image": (IMAGE, [C.c_int, C.c_int, C.c_int]),
+    "free_image": (None, [IMAGE]),
+    "make_network_boxes": (C.POINTER(DETECTION), [C.c_void_p, C.c_float, C.POINTER(C.c_int)]),
+    "free_ptrs": (None, [C.POINTER(C.c_void_p), C.c_int]),
+    "reset_rnn": (None, [C.c_void_p]),
+    "set_batch_network": (None, [C.c_void_p, C.c_int]),
+    "letterbox_image": (IMAGE, [IMAGE, C.c_int, C.c_int]),
+    "get_metadata": (METADATA, [C.c_char_p]),
+    "load_image_color": (IMAGE, [C.c_char_p, C.c_int, C.c_int]),
+    "rgbgr_image": (None, [IMAGE]),
 }
 
 
@@ -69,6 +86,23 @@ def free_net(net):
     _load().free_network(net)
 
 
+def load_meta(path):
+    """D2T/darknet.py:101-103."""
+    return _load().get_metadata(os.fsencode(path))
+
+
+def load_image(path, w=0, h=0):
+    """D2T/darknet.py:105-107 (binary PPM / PGM files)."""
+    im = _load().load_image_color(os.fsencode(path), w, h)
+    if not im.data:
+        raise YoloError("load_image_color failed for %s" % path)
+    return im
+
+
+def set_gpu(n):
+    _load().cuda_set_device(n)
+
+
 def array_to_image(arr):
     """HWC RGB uint8 (0..255) or float (0..1) -> darknet IMAGE (planar float 0..1); keeps the buffer alive on the result."""
     a = np.asarray(arr)
@@ -87,9 +121,13 @@ def predict_image(net, im):
 
 
 def detect(net, names, image, thresh=.5, hier_thresh=.5, nms=.45):
-    """D2T/darknet.py:125-142 with `image` an array / IMAGE and `names` the class-name list (meta.names)."""
+    """D2T/darknet.py:125-142; `image`: a PPM path (as the reference passes a file name), an array or an IMAGE; `names`: a
+    METADATA (load_meta) or the class-name list."""
     l = _load()
-    im = image if isinstance(image, IMAGE) else array_to_image(image)
+    own = isinstance(image, (str, bytes))
+    im = load_image(image, 0, 0) if own else image if isinstance(image, IMAGE) else array_to_image(image)
+    if isinstance(names, METADATA):
+        names = [names.names[i] for i in range(names.classes)]
     num = C.c_int(0)
     predict_image(net, im)
     dets = l.get_network_boxes(net, im.w, im.h, thresh, hier_thresh, None, 0, C.byref(num))
@@ -104,5 +142,7 @@ def detect(net, names, image, thresh=.5, hier_thresh=.5, nms=.45):
                 b = dets[j].bbox
                 res.append((names[i], dets[j].prob[i], (b.x, b.y, b.w, b.h)))
     res = sorted(res, key=lambda x: -x[1])
+    if own:
+        l.free_image(im)
     l.free_detections(dets, n)
     return res

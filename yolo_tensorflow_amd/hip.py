@@ -28,6 +28,7 @@ EXPORTS = [
     "yolo_conv_flops", "yolo_conv_bytes", "yolo_forward", "yolo_forward_image_u8", "yolo_postprocess",
     "yolo_detect", "yolo_detect_graph", "yolo_synchronize", "yolo_layer_output", "yolo_time_forward", "yolo_time_layers",
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
+    "yolo_darknet_boxes", "yolo_last_layer_size", "yolo_last_layer_output", "yolo_op_letterbox",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
 ]
 
@@ -92,6 +93,10 @@ def load_library():
     l.yolo_op_nms_detections.argtypes = [P, P, P, I, I, F, I, I]
     l.yolo_forward_letterbox_chw.argtypes = [P, P, I, I, I, P, I]
     l.yolo_op_decode.argtypes = [P, I, I, I, I, P, I, I, I, P, I]
+    l.yolo_darknet_boxes.argtypes = [P, I, I, F, I, P, I, P]
+    l.yolo_last_layer_size.argtypes = [P]; l.yolo_last_layer_size.restype = C.c_size_t
+    l.yolo_last_layer_output.argtypes = [P, P, C.c_size_t]
+    l.yolo_op_letterbox.argtypes = [P, I, I, I, I, I, P, I]
     l.yolo_op_postprocess.argtypes = [P, I, I, I, F, F, I, I, I, P, P, I]
     _lib = l
     return l
