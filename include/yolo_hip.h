@@ -63,6 +63,9 @@ enum yolo_nms_mode {
     YOLO_NMS_TF = 0,           /* tf.image.non_max_suppression: class-agnostic, `>` iou, top max_out (row N1) */
     YOLO_NMS_PER_CLASS = 1,    /* V2 bboxes_nms (V2/utils.py:176-187): same-class, drop unless iou < thr (row N3) */
     YOLO_NMS_DARKNET = 2,      /* do_nms_sort (DN/box.c:58-89) on max-class score: same-class, drop if iou > thr */
+    YOLO_NMS_TF_V1 = 4,        /* YOLOv1's call of tf.image.non_max_suppression (V1/YOLO_V1_Inference.py:259-266): as YOLO_NMS_TF on
+                                * boxes whose horizontal extent is built from h and vertical extent from w (the reference's swap);
+                                * the records hold those corners: centre = their midpoint, w = y1 - y0, h = x1 - x0 */
     YOLO_NMS_NUMPY_V3 = 3      /* `non_max_suppression` V3/yolo_v3.py:376-420 (row N2): gate on objectness > thr, class =
                                 * argmax cls, per class by objectness, keep iou < thr with the unclamped `_iou`; reported
                                 * score reproduces the reference's shifted-index behaviour.  Records come out class by

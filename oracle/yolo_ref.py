@@ -188,6 +188,9 @@ def conv_layers(secs):
             out.append(dict(idx=i, filters=int(s["filters"]), size=int(s["size"]),
                             stride=int(s.get("stride", 1)), bn=int(s.get("batch_normalize", 0)),
                             act=s.get("activation", "logistic"), cin=shp["cin"]))
+        elif s["type"] == "connected":       # parameters are stored like a bias conv's: biases, then weights [output][inputs]
+            out.append(dict(idx=i, filters=int(s["output"]), size=1, stride=1, bn=0,
+                            act=s.get("activation", "logistic"), cin=shp["cin"]))
     return out
 
 
@@ -215,7 +218,10 @@ def _walk_shapes(secs):
             ls = [l if l >= 0 else i + l for l in ls]
             H, W = shapes[ls[0]][0], shapes[ls[0]][1]
             C = sum(shapes[l][2] for l in ls)
-        elif t == "shortcut":
+        elif t == "connected":               # DN/connected_layer.c:151 / slim.flatten + fully_connected (V1/YOLO_V1_Inference.py:198-206)
+            cin = H * W * C
+            H, W, C = 1, 1, int(s["output"])
+        elif t in ("shortcut", "dropout"):
             pass
         elif t in ("yolo", "region", "detection"):
             pass
@@ -515,6 +521,32 @@ def v1_decode(predicts, S=7, B=2, C=20, threshold=0.2):
     return boxes[m].astype(np.float32), smax[m], label[m]
 
 
+def v1_rows(predicts, S=7, B=2, C=20, sqr=True):
+    """The same decode as rows [S*S*B, 5+C] = (cx, cy, w, h, conf, cls...) of EVERY box, batch element `predicts` [P]: the layout the
+    device keeps (cell-major, box inside the cell)."""
+    p = np.asarray(predicts, dtype=np.float32).reshape(-1)
+    idx1 = S * S * C; idx2 = idx1 + S * S * B
+    cls = p[:idx1].reshape(S * S, C); conf = p[idx1:idx2].reshape(S * S, B); box = p[idx2:].reshape(S * S, B, 4)
+    col = (np.arange(S * S) % S).astype(np.float32)[:, None]; row = (np.arange(S * S) // S).astype(np.float32)[:, None]
+    out = np.zeros((S * S, B, 5 + C), np.float32)
+    out[..., 0] = (box[..., 0] + col) / np.float32(S); out[..., 1] = (box[..., 1] + row) / np.float32(S)
+    out[..., 2] = np.square(box[..., 2]) if sqr else box[..., 2]; out[..., 3] = np.square(box[..., 3]) if sqr else box[..., 3]
+    out[..., 4] = conf; out[..., 5:] = cls[:, None, :]
+    return out.reshape(S * S * B, 5 + C)
+
+
+def detect_v1_tf(predicts, S=7, B=2, C=20, threshold=0.2, iou_threshold=0.4, max_output_size=10):
+    """V1 `_build_detector` complete (V1/YOLO_V1_Inference.py:213-270): decode, `>=` threshold, then
+    tf.image.non_max_suppression on `_boxes` = [y - w/2, x - h/2, y + w/2, x + h/2] -- the reference builds the vertical
+    extent from the width and the horizontal one from the height (:259-262); kept verbatim.  -> (boxes cxcywh, scores, classes)."""
+    boxes, scores, classes = v1_decode(np.asarray(predicts, np.float32).reshape(1, -1), S, B, C, threshold)
+    f = np.float32
+    _b = np.stack([boxes[:, 1] - f(0.5) * boxes[:, 2], boxes[:, 0] - f(0.5) * boxes[:, 3],
+                   boxes[:, 1] + f(0.5) * boxes[:, 2], boxes[:, 0] + f(0.5) * boxes[:, 3]], axis=1).astype(np.float32)
+    sel = tf_nms(_b, scores, max_output_size, iou_threshold)
+    return boxes[sel], scores[sel], classes[sel]
+
+
 # ----------------------------------------------------------------------------------------------
 # rows N1, N2, N3 (+ darknet do_nms_sort): NMS flavours
 # ----------------------------------------------------------------------------------------------
@@ -700,7 +732,28 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
     ci = 0
     for i, s in enumerate(layers):
         t = s["type"]
-        if t == "convolutional":
+        if t == "connected":
+            # Net1's head (V1/YOLO_V1_Inference.py:196-206): NHWC -> NCHW transpose, flatten, x @ W + b; darknet's [connected]
+            # (DN/connected_layer.c:151-166) is the same product on its CHW tensors.  Stored here as [N,1,1,output].
+            p = params[ci]; ci += 1
+            is_head = i + 1 < len(layers) and layers[i + 1]["type"] == "detection"
+            w = p["w_hwio"].reshape(-1, p["w_hwio"].shape[-1])            # [inputs (CHW order), output]
+            flat = np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2))).reshape(x.shape[0], -1)
+            y = (flat @ (to_bf16(w) if emulate_bf16 else w) + p["bias"]).astype(np.float32)
+            act = s.get("activation", "logistic")
+            if act == "leaky":
+                y = leaky_relu(y)
+            elif act != "linear":
+                raise ValueError(act)
+            y = y.reshape(x.shape[0], 1, 1, -1)
+            x = y if is_head else q(y)
+        elif t == "dropout":
+            pass                                                          # inference: identity (is_training=False, :203-204)
+        elif t == "detection":
+            heads.append((s, outs[i - 1]))
+            outs.append(None)
+            continue
+        elif t == "convolutional":
             p = params[ci]; ci += 1
             k, st = int(s["size"]), int(s.get("stride", 1))
             is_head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")

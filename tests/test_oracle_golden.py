@@ -109,3 +109,27 @@ def test_region_decode_matches_darknet_boxes():
     prob = obj.reshape(-1, 1) * cls.reshape(-1, cls.shape[-1])
     thresh = float(g["thresh"])
     np.testing.assert_allclose(np.where(prob > thresh, prob, 0), g["prob_raw"], rtol=1e-4, atol=1e-6)
+
+
+def test_v1_restatement_matches_compiled_reference():
+    """Rows Net1 / D1: the oracle's [connected] (CHW flatten), 7x7/2 conv, [dropout] and [detection] decode against every layer
+    output and get_network_boxes of the reference's own C code (tests/golden/mini_v1.npz, tools/make_golden.py gen_mini_v1)."""
+    g = golden("mini_v1.npz")
+    cfg = str(g["cfg"])
+    secs = R.parse_cfg(cfg); params = R.unflatten_weights(g["weights"], secs)
+    x = (g["image_u8"].astype(np.float32) / np.float32(255)) * np.float32(2) - np.float32(1)
+    heads, outs = R.forward(secs, params, x[None], collect=True)
+    for i, o in enumerate(outs):
+        if o is not None:
+            ref = g["layer_%02d" % i].reshape(o.shape)
+            assert np.abs(o - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), "layer %d" % i
+    rows = R.v1_rows(heads[0][1][0], 3, 2, 20)
+    np.testing.assert_allclose(rows[:, :4] * np.float32(64), g["boxes_raw"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], g["obj_raw"], rtol=1e-6, atol=1e-7)
+    pr = rows[:, 4:5] * rows[:, 5:]
+    np.testing.assert_allclose(np.where(pr > g["thresh"], pr, 0), g["prob_raw"], rtol=1e-5, atol=1e-6)
+    # and the TF-side detector on the same predictions: v1_decode is the thresholded subset of v1_rows, best-first after the NMS
+    b, s, c = R.detect_v1_tf(heads[0][1][0].reshape(-1), 3, 2, 20, 0.2, 0.4, 10)
+    full = R.v1_rows(heads[0][1][0], 3, 2, 20)
+    smax = (full[:, 4:5] * full[:, 5:]).max(-1)
+    assert len(s) > 0 and (np.diff(s) <= 0).all() and set(np.round(s, 6)).issubset(set(np.round(smax[smax >= 0.2], 6)))

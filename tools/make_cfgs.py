@@ -7,6 +7,9 @@ reference's layer tables and TF graph builders:
   yolov3-tiny     D2T/YOLO_V3_Tiny_convert_darkenet_to_Tensorflow.py:376-465 (anchors :29)
   yolov2          V2/yolov2.txt:2-32   == V2/model_darknet19_slim.py:119-200 (anchors V2/config.py:7-11)
   yolov2-tiny-voc D2T/YOLO_V2_Tiny_Voc_convert_darkenet_to_Tensorflow.py:162-225
+  yolov1          V1/YOLO_V1_Inference.py:124-210 (`_build_network`: 24 bias convs, 7x7/2 first, four SAME pools, CHW flatten,
+                  FC 50176 -> 512 -> 4096 -> 1470) + :213-270 ([detection]: side 7, 2 boxes, 20 classes, sqrt sizes); the two
+                  `yolo_input_*` keys of [net] state its input normalisation (x/255)*2-1 (:67-71) for the HIP planner (darknet ignores them)
 The key names are the ones the reference's cfg parser reads (DN/parser.c:177-205 convolutional,
 :303-339 yolo, :341-391 region, :471-486 maxpool, :527-545 shortcut, :580-587 upsample,
 :589-628 route, reorg :447-459), so the same text drives three consumers: the HIP library's
@@ -20,9 +23,9 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tenso
 
 
 class Cfg:
-    def __init__(self, size, channels=3):
+    def __init__(self, size, channels=3, extra=()):
         self.lines = ["[net]", "batch=1", "subdivisions=1", f"width={size}", f"height={size}",
-                      f"channels={channels}", ""]
+                      f"channels={channels}"] + list(extra) + [""]
         self.n = 0  # next layer index
 
     def _sec(self, name, **kv):
@@ -66,6 +69,16 @@ class Cfg:
                          bias_match=1, classes=classes, coords=4, num=len(anchors), softmax=1,
                          jitter=.3, rescore=1, object_scale=5, noobject_scale=1, class_scale=1,
                          coord_scale=1, absolute=1, thresh=.6, random=0)
+
+    def connected(self, output, act="leaky"):
+        return self._sec("connected", output=output, activation=act)
+
+    def dropout(self, p=.5):
+        return self._sec("dropout", probability=p)
+
+    def detection(self, classes=20, side=7, num=2):
+        return self._sec("detection", classes=classes, coords=4, rescore=1, side=side, num=num, softmax=0, sqrt=1,
+                         jitter=.2, object_scale=1, noobject_scale=.5, class_scale=1, coord_scale=5)
 
     def text(self):
         return "\n".join(self.lines)
@@ -164,9 +177,27 @@ def yolov2_tiny_voc(size=416, classes=20):
     return c.text()
 
 
+def yolov1(size=448, classes=20):
+    c = Cfg(size, extra=("yolo_input_mul=2", "yolo_input_add=-1"))
+    b = dict(bn=False)
+    c.conv(64, 7, stride=2, **b); c.maxpool()
+    c.conv(192, 3, **b); c.maxpool()
+    c.conv(128, 1, **b); c.conv(256, 3, **b); c.conv(256, 1, **b); c.conv(512, 3, **b); c.maxpool()
+    for _ in range(4):
+        c.conv(256, 1, **b); c.conv(512, 3, **b)
+    c.conv(512, 1, **b); c.conv(1024, 3, **b); c.maxpool()
+    for _ in range(2):
+        c.conv(512, 1, **b); c.conv(1024, 3, **b)
+    c.conv(1024, 3, **b); c.conv(1024, 3, stride=2, **b); c.conv(1024, 3, **b); c.conv(1024, 3, **b)
+    c.connected(512); c.connected(4096); c.dropout(); c.connected(7 * 7 * (classes + 2 * 5), act="linear")
+    c.detection(classes, 7, 2)
+    return c.text()
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     files = {
+        "yolov1.cfg": yolov1(448),
         "yolov3.cfg": yolov3(416), "yolov3-608.cfg": yolov3(608),
         "yolov3-tiny.cfg": yolov3_tiny(416),
         "yolov2.cfg": yolov2(416), "yolov2-tiny-voc.cfg": yolov2_tiny_voc(416),

@@ -330,6 +330,88 @@ def gen_v2_post():
     print("v2_postprocess: kept", len(out_s))
 
 
+MINI_V1 = """[net]
+batch=1
+width=64
+height=64
+channels=3
+
+[convolutional]
+filters=16
+size=7
+stride=2
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[connected]
+output=96
+activation=leaky
+
+[dropout]
+probability=.5
+
+[connected]
+output=270
+activation=linear
+
+[detection]
+classes=20
+coords=4
+rescore=1
+side=3
+num=2
+softmax=0
+sqrt=1
+"""
+
+
+def gen_mini_v1():
+    """YOLOv1-style topology (7x7/2 bias conv, SAME pools, [connected] x2 with a [dropout] between, [detection]) through the
+    compiled reference: every layer output, and get_network_boxes -> get_detection_detections (DN/detection_layer.c:225-254).
+    The input is already in the reference's (x/255)*2-1 range (V1/YOLO_V1_Inference.py:67-71)."""
+    from oracle import darknet_ref as D
+    from yolo_tensorflow_amd import darknet_io as IO
+    secs = IO.parse_cfg(MINI_V1)
+    flat = IO.synth_weights(secs, seed=9)
+    net = D.RefNet(MINI_V1, flat, 0, 1)
+    rng = np.random.default_rng(13)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    x = (img.astype(np.float32) / np.float32(255.0)) * np.float32(2) - np.float32(1)
+    net.predict(x)
+    data = {"cfg": np.array(MINI_V1), "weights": flat, "image_u8": img, "header": np.array([0, 1])}
+    for i in range(net.n):
+        data["layer_%02d" % i] = net.layer_output_nhwc(i).astype(np.float32)
+    thresh = 0.2
+    bb, obj, pr = net.boxes(thresh, None, 20)
+    data["boxes_raw"], data["obj_raw"], data["prob_raw"] = bb, obj, pr
+    data["thresh"] = np.float32(thresh)
+    np.savez_compressed(os.path.join(OUT, "mini_v1.npz"), **data)
+    print("mini_v1 layers", net.n, "boxes", len(bb), "nonzero probs", int((pr > 0).sum()))
+    net.close()
+
+
 def gen_mini(name, cfg, classes, nms_thresh=0.3, thresh=0.15):
     from oracle import darknet_ref as D
     from yolo_tensorflow_amd import darknet_io as IO
@@ -362,3 +444,4 @@ if __name__ == "__main__":
     gen_v2_post()
     gen_mini("mini_v3", MINI_V3, 4)
     gen_mini("mini_v2", MINI_V2, 5)
+    gen_mini_v1()

@@ -85,7 +85,7 @@ static inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)(
 
 // ---- row P: uint8/float image at network size -> 8-channel (3 real + 5 zero) activation ---------
 template <typename T>
-__global__ void k_preprocess(const void *img, int fmt, size_t npix, size_t hw, float scale, T *out, int out_stride)
+__global__ void k_preprocess(const void *img, int fmt, size_t npix, size_t hw, float scale, T *out, int out_stride, float post_mul, float post_add)
 {
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -101,20 +101,22 @@ __global__ void k_preprocess(const void *img, int fmt, size_t npix, size_t hw, f
         const float *s = (const float *)img + b * 3 * hw + q;
         v[0] = s[0] * scale; v[1] = s[hw] * scale; v[2] = s[2 * hw] * scale;
     }
+    // YOLOv1's input normalisation `(x / 255) * 2 - 1` (V1/YOLO_V1_Inference.py:67-71): an affine map of the three real channels
+    if (post_mul != 1.0f || post_add != 0.0f) { v[0] = v[0] * post_mul + post_add; v[1] = v[1] * post_mul + post_add; v[2] = v[2] * post_mul + post_add; }
     Elt<T>::store8(out + p * out_stride, v);
 }
 
 hipError_t launch_preprocess(const void *img, int fmt, int n, int hw, float scale, void *out, int out_dt,
-                             int out_stride, hipStream_t s)
+                             int out_stride, hipStream_t s, float post_mul, float post_add)
 {
     size_t npix = (size_t)n * hw;
-    WITH_DT(out_dt, hipLaunchKernelGGL(k_preprocess<T>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, (size_t)hw, scale, (T *)out, out_stride));
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_preprocess<T>, grid_for(npix), dim3(256), 0, s, img, fmt, npix, (size_t)hw, scale, (T *)out, out_stride, post_mul, post_add));
     return hipGetLastError();
 }
 
 // legacy TF bilinear (no half-pixel offset): src = dst * (in/out); value/255 first (D2T _input_process)
 template <typename T>
-__global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, int out_stride, int out_c, float post_scale)
+__global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, int out_stride, int out_c, float post_scale, float post_add)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= so * so) return;
@@ -135,6 +137,7 @@ __global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, in
         float bot = bl + (br - bl) * xl;
         v[c] = top + (bot - top) * yl;
         if (post_scale != 1.0f) v[c] *= post_scale;
+        if (post_add != 0.0f) v[c] += post_add;
     }
     if (out_c >= 8) Elt<T>::store8(out + (size_t)p * out_stride, v);
     else
@@ -142,10 +145,10 @@ __global__ void k_resize_u8(const uint8_t *img, int h, int w, int so, T *out, in
 }
 
 hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_dt, int out_stride,
-                            int out_c, hipStream_t s, float post_scale)
+                            int out_c, hipStream_t s, float post_scale, float post_add)
 {
     size_t np = (size_t)s_out * s_out;
-    WITH_DT(out_dt, hipLaunchKernelGGL(k_resize_u8<T>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (T *)out, out_stride, out_c, post_scale));
+    WITH_DT(out_dt, hipLaunchKernelGGL(k_resize_u8<T>, grid_for(np), dim3(256), 0, s, img, h, w, s_out, (T *)out, out_stride, out_c, post_scale, post_add));
     return hipGetLastError();
 }
 

@@ -115,9 +115,9 @@ hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 
 // ---- memory-bound operators (ew_ops.hip) ------------------------------------------------------
 hipError_t launch_preprocess(const void *img, int fmt /*0 u8, 1 f32*/, int n, int hw, float scale,
-                             void *out, int out_dt, int out_stride, hipStream_t s);
+                             void *out, int out_dt, int out_stride, hipStream_t s, float post_mul = 1.0f, float post_add = 0.0f);
 hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_dt,
-                            int out_stride, int out_c, hipStream_t s, float post_scale = 1.0f);
+                            int out_stride, int out_c, hipStream_t s, float post_scale = 1.0f, float post_add = 0.0f);
 hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s);
 hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s);
 hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s);
@@ -140,6 +140,9 @@ struct DecodeArgs {
 };
 // scores/labels (nullable): per-row max_k(obj*cls_k) and its first argmax, written alongside the decode
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s);
+// YOLOv1 [detection] head (row D1): raw [n][raw_stride] fp32 = [cls S*S*C | conf S*S*B | box S*S*B*4] -> det rows (cx, cy, w, h, conf, cls...)
+hipError_t launch_decode_v1(const float *raw, int raw_stride, int n, int side, int num, int classes, int sqr, float *det, int rows_total,
+                            int row_off, float *scores, int *labels, hipStream_t s);
 
 struct PostArgs {
     const float *det; int n, rows, attrs;

@@ -259,6 +259,39 @@ __global__ void k_decode_region(const DecodeArgs a)
     for (int k = 0; k < a.classes; ++k) o[5 + k] = expf(p[5 + k] - mx) / sum;
 }
 
+// ---- D1: YOLOv1 `_build_detector` before the selection (V1/YOLO_V1_Inference.py:213-244; darknet twin get_detection_detections
+//      DN/detection_layer.c:225-254): x = (bx + col) / S, y = (by + row) / S, w = bw^2, h = bh^2 (`tf.square`, darknet's sqrt=1),
+//      class-specific score = conf * cls, label = first arg-max.  98 boxes per image: one thread per box. ----
+__global__ void k_decode_v1(const float *raw, int raw_stride, int n, int S, int B, int C, int sqr, float *det, int rows_total, int row_off,
+                            float *scores, int *labels)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = S * S * B;
+    if (i >= n * per) return;
+    const int img = i / per, r = i - img * per, cell = r / B, b = r - cell * B;
+    const float *p = raw + (size_t)img * raw_stride;
+    const float *cls = p + cell * C, *box = p + S * S * (C + B) + (cell * B + b) * 4;
+    const float conf = p[S * S * C + cell * B + b];
+    const int attrs = 5 + C;
+    const size_t row = (size_t)img * rows_total + row_off + r;
+    float *o = det + row * attrs;
+    o[0] = (box[0] + (float)(cell % S)) / (float)S;
+    o[1] = (box[1] + (float)(cell / S)) / (float)S;
+    o[2] = sqr ? box[2] * box[2] : box[2];
+    o[3] = sqr ? box[3] * box[3] : box[3];
+    o[4] = conf;
+    float best = -INFINITY; int bi = 0;
+    for (int k = 0; k < C; ++k) { const float c = cls[k]; o[5 + k] = c; const float sc = conf * c; if (sc > best) { best = sc; bi = k; } }
+    if (scores) { scores[row] = best; labels[row] = bi; }
+}
+hipError_t launch_decode_v1(const float *raw, int raw_stride, int n, int side, int num, int classes, int sqr, float *det, int rows_total,
+                            int row_off, float *scores, int *labels, hipStream_t s)
+{
+    const int total = n * side * side * num;
+    hipLaunchKernelGGL(k_decode_v1, dim3((total + 127) / 128), dim3(128), 0, s, raw, raw_stride, n, side, num, classes, sqr, det, rows_total, row_off, scores, labels);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s)
 {
     // the lean form (no decoded tensor) exists in the cell-per-wave kernel only
@@ -441,7 +474,12 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
         const float *p = a.box4 ? a.box4 + ((size_t)img * a.rows + row) * 4 : a.det + ((size_t)img * a.rows + row) * a.attrs;
         float4 b;
         if (a.nms_mode == 2 || a.corners_in) b = float4{p[0], p[1], p[2], p[3]};       // (cx,cy,w,h) for darknet; given corners
-        else {
+        else if (a.nms_mode == 4) {
+            // YOLOv1's quirk (V1/YOLO_V1_Inference.py:259-262): `_boxes` = [y - w/2, x - h/2, y + w/2, x + h/2] handed over as
+            // [ymin, xmin, ymax, xmax] -- the vertical extent is built from the WIDTH and the horizontal one from the HEIGHT
+            float w2 = 0.5f * p[2], h2 = 0.5f * p[3];
+            b = float4{p[0] - h2, p[1] - w2, p[0] + h2, p[1] + w2};
+        } else {
             float w2 = p[2] * 0.5f, h2 = p[3] * 0.5f;                                      // V3/YOLOV3.py:348-351
             b = float4{p[0] - w2, p[1] - h2, p[0] + w2, p[1] + h2};
         }
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
         }
         __syncthreads();
         const int cur = s_cur, kept = s_kept;
-        if (cur < 0 || (a.nms_mode == 0 && kept >= a.max_out)) break;
+        if (cur < 0 || ((a.nms_mode == 0 || a.nms_mode == 4) && kept >= a.max_out)) break;
         const float4 bc = sbox[cur];
         const int lc = slabel[cur];
         if (tid == 0) {
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
         for (int j = cur + 1 + tid; j < M; j += NMS_THREADS) {
             if (!((alive[j >> 5] >> (j & 31)) & 1u)) continue;
             bool kill;
-            if (a.nms_mode == 0) kill = iou_tf(bc, sbox[j]) > a.iou_thr;
+            if (a.nms_mode == 0 || a.nms_mode == 4) kill = iou_tf(bc, sbox[j]) > a.iou_thr;
             else if (a.nms_mode == 2) kill = slabel[j] == lc && iou_darknet(bc, sbox[j]) > a.iou_thr;
             else {
                 float4 bj = sbox[j];

@@ -24,7 +24,7 @@
 
 namespace {
 
-enum LType { L_CONV, L_SHORTCUT, L_ROUTE, L_UPSAMPLE, L_MAXPOOL, L_REORG, L_YOLO, L_REGION };
+enum LType { L_CONV, L_SHORTCUT, L_ROUTE, L_UPSAMPLE, L_MAXPOOL, L_REORG, L_YOLO, L_REGION, L_DETECT };
 
 struct Section { std::string type; std::map<std::string, std::string> kv; };
 
@@ -43,6 +43,12 @@ struct Layer {
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one
+    // [connected] (YOLOv1's fully connected head, V1/YOLO_V1_Inference.py:196-206; DN/connected_layer.c:151): a 1x1 conv over the
+    // producer's tensor flattened to one pixel per image; fc_h/w/c = the producer's geometry (darknet / the TF graph flatten CHW)
+    bool fc = false; int fc_h = 0, fc_w = 0, fc_c = 0;
+    // 7x7 / stride 2 / pad 3 first conv (YOLOv1): computed as a 4x4 / stride 1 conv over the 2x2 space-to-depth of the input
+    bool s2d7 = false;
+    int side = 0, sqr = 0;                  // [detection] head
     // fused 1x1 tail of the tiled conv kernel: `tail_layer` (on the producer) = index of the 1x1 conv that can be computed
     // in the producer's epilogue, `fused_into` (on that 1x1) = the producer; `tail_on` = the plan uses it
     int tail_layer = -1, fused_into = -1; bool tail_on = false;
@@ -76,6 +82,8 @@ struct yolo_ctx {
     TView input;                          // [n, S, S, 8]
     void *d_zeros = nullptr;
     void *d_stage = nullptr; size_t stage_bytes = 0;     // host->device image staging
+    TView s2d;                            // [n, S/2, S/2, 32]: space-to-depth of the input for a 7x7/2 first conv
+    float in_mul = 1.f, in_add = 0.f;     // input normalisation after the /255: v * in_mul + in_add ([net] yolo_input_mul / yolo_input_add)
     float *d_det = nullptr; int rows = 0, attrs = 0;
     // lean detect path (yolo_detect*): the decode writes scores, labels and the four box numbers of every row, not the tensor
     float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false;
@@ -201,14 +209,41 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             std::string act = opt_s(s, "activation", "logistic");
             if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
             else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
-            if (L.size != 1 && L.size != 3) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: conv size %d unsupported on the device path", i, L.size);
+            if (L.size == 7 && L.stride == 2 && L.pad == 3 && i == 0 && C == 3 && H % 2 == 0 && W % 2 == 0 && c->dtype != YOLO_FP8) L.s2d7 = true;
+            else if (L.size != 1 && L.size != 3) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: conv size %d unsupported on the device path", i, L.size);
             // fp8 mode: the first conv still reads the bf16 image (3 real channels padded to 8) with bf16 filters
             L.in_dt = c->dtype == YOLO_FP8 ? (i == 0 ? DT_BF16 : DT_FP8) : c->act_dt();
             L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
             L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
+            if (L.s2d7) { L.cin_pad = 32; L.kpad = 16 * 32; }          // 4x4 taps x (2x2 positions x 8 padded channels)
             H = (H + 2 * L.pad - L.size) / L.stride + 1; W = (W + 2 * L.pad - L.size) / L.stride + 1; C = L.filters;
             c->conv_flops += 2.0 * L.size * L.size * L.cin * L.filters * (double)H * W;
             c->weights_count += (size_t)L.filters * (L.bn ? 4 : 1) + (size_t)L.filters * L.cin * L.size * L.size;
+        } else if (s.type == "connected") {
+            if (c->dtype == YOLO_FP8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [connected] is not served in the fp8 configuration", i);
+            if (opt_i(s, "batch_normalize", 0)) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: batch-normalised [connected]", i);
+            L.type = L_CONV; L.fc = true; L.fc_h = H; L.fc_w = W; L.fc_c = C;
+            L.filters = opt_i(s, "output", 1); L.size = 1; L.stride = 1; L.pad = 0; L.bn = 0;
+            std::string act = opt_s(s, "activation", "logistic");
+            if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
+            else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
+            L.in_dt = c->act_dt();
+            if ((long)H * W * C > (1L << 24)) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [connected] input too large", i);
+            L.cin = H * W * C; L.cin_pad = roundup(L.cin, 8); L.kpad = roundup(L.cin_pad, 64); L.cout_pad = roundup(L.filters, 256);
+            c->conv_flops += 2.0 * L.cin * L.filters;
+            c->weights_count += (size_t)L.filters + (size_t)L.filters * L.cin;
+            H = 1; W = 1; C = L.filters;
+        } else if (s.type == "dropout") {
+            L.type = L_ROUTE;                       // inference: identity (DN/dropout_layer.c:38-40)
+        } else if (s.type == "detection") {
+            L.type = L_DETECT; L.classes = opt_i(s, "classes", 1); L.na = opt_i(s, "num", 1); L.side = opt_i(s, "side", 7); L.sqr = opt_i(s, "sqrt", 0);
+            if (opt_i(s, "coords", 4) != 4 || opt_i(s, "softmax", 0)) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [detection] with coords != 4 or softmax", i);
+            if (i == 0 || !c->layers[i - 1].fc) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [detection] must follow a [connected] layer", i);
+            if (C != L.side * L.side * (L.classes + L.na * 5)) return fail(c, YOLO_ERR_INVALID, "layer %d: [detection] expects %d inputs, got %d", i, L.side * L.side * (L.classes + L.na * 5), C);
+            if (c->attrs && c->attrs != 5 + L.classes) return fail(c, YOLO_ERR_UNSUPPORTED, "heads with different class counts");
+            c->attrs = 5 + L.classes; L.row_off = c->rows; c->rows += L.side * L.side * L.na;
+            c->layers[i - 1].head = true;
+            H = L.side; W = L.side;
         } else if (s.type == "shortcut") {
             L.type = L_SHORTCUT; int f = opt_i(s, "from", -1); f = f < 0 ? i + f : f;
             if (f < 0 || f >= i) return fail(c, YOLO_ERR_INVALID, "layer %d: bad shortcut from", i);
@@ -262,7 +297,8 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         }
         L.H = H; L.W = W; L.C = C;
     }
-    if (c->rows == 0) return fail(c, YOLO_ERR_INVALID, "cfg has no [yolo]/[region] head");
+    if (c->rows == 0) return fail(c, YOLO_ERR_INVALID, "cfg has no [yolo] / [region] / [detection] head");
+    c->in_mul = (float)atof(opt_s(net, "yolo_input_mul", "1").c_str()); c->in_add = (float)atof(opt_s(net, "yolo_input_add", "0").c_str());
     if (c->rows > 32768) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 32768 candidates per image");
 
     // ---- use counts, shortcut fusion, concat placement ----
@@ -284,7 +320,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             c->layers[0].stem_skip = true; c->layers[1].stem = true;
             if (NL >= 3) {
                 const Layer &T = c->layers[2];
-                if (T.type == L_CONV && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1)
+                if (T.type == L_CONV && !T.fc && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1)
                     c->layers[2].stem_tail = true;
             }
         }
@@ -300,13 +336,13 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     if ((c->dtype == YOLO_BF16 || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
-            if (P.type != L_CONV || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
+            if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
             int o = i;
             if (P.residual_from >= -1) o = i + 1;            // its shortcut was folded into it: consumers read layer i+1
             const int j = o + 1;
             if (j >= NL) continue;
             Layer &T = c->layers[j];
-            if (T.type == L_CONV && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
+            if (T.type == L_CONV && !T.fc && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
                 T.residual_from < -1 && !T.stem_tail) { P.tail_layer = j; T.fused_into = i; }
         }
     }
@@ -319,7 +355,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
             bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
-                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && (cj % c->gran() == 0) && (off % c->gran() == 0);
+                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % c->gran() == 0) && (off % c->gran() == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
             if (ok) { place_route[j] = i; place_off[j] = off; }
@@ -340,7 +376,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     }
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type == L_YOLO || L.type == L_REGION) { L.noop = true; L.storage = c->layers[i - 1].storage; L.ch_off = c->layers[i - 1].ch_off; continue; }
+        if (L.type == L_YOLO || L.type == L_REGION || L.type == L_DETECT) { L.noop = true; L.storage = c->layers[i - 1].storage; L.ch_off = c->layers[i - 1].ch_off; continue; }
         if (L.type == L_ROUTE && L.in.size() == 1) { L.noop = true; int j = L.in[0]; if (j < 0) return fail(c, YOLO_ERR_UNSUPPORTED, "route to network input"); L.storage = c->layers[j].storage; L.ch_off = c->layers[j].ch_off; continue; }
         if (L.type == L_ROUTE) continue;
         if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
@@ -409,6 +445,17 @@ int allocate(yolo_ctx *c)
     HIPCK(c, hipMalloc(&c->input.ptr, in_bytes));
     c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8;
     HIPCK(c, hipMalloc(&c->d_zeros, 4096)); HIPCK(c, hipMemsetAsync(c->d_zeros, 0, 4096, c->stream));
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        const Layer &L = c->layers[i];
+        if (L.s2d7) {
+            c->s2d = c->input; c->s2d.h = c->in_h / 2; c->s2d.w = c->in_w / 2; c->s2d.c = 32; c->s2d.stride = 32;
+            HIPCK(c, hipMalloc(&c->s2d.ptr, (size_t)c->max_batch * c->s2d.h * c->s2d.w * 32 * dt_size(c->s2d.dt)));
+        }
+        if (L.fc) {             // the flattened producer must be dense: one pixel of fc_h * fc_w * fc_c contiguous elements per image
+            const TView in = view_of(c, L.in[0]);
+            if (in.stride != in.c || in.c != L.fc_c) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %zu: [connected] needs a dense producer (channels a multiple of 8, not part of a concat)", i);
+        }
+    }
     c->stage_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 3 * 4;
     HIPCK(c, hipMalloc(&c->d_stage, c->stage_bytes));
     size_t nr = (size_t)c->max_batch * c->rows;
@@ -416,7 +463,7 @@ int allocate(yolo_ctx *c)
     HIPCK(c, hipMalloc((void **)&c->d_box4, nr * 16));
     c->lean_ok = true;                  // every head a [yolo] head the cell-per-wave decode serves
     for (auto &L : c->layers) {
-        if (L.type == L_REGION) c->lean_ok = false;
+        if (L.type == L_REGION || L.type == L_DETECT) c->lean_ok = false;
         if (L.type == L_YOLO && L.na * (5 + L.classes) > 256) c->lean_ok = false;
     }
     c->rows_pow2 = 1; while (c->rows_pow2 < c->rows) c->rows_pow2 <<= 1;
@@ -457,6 +504,8 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     }
     a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
     a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, L.in_dt); a.act = L.act; a.zeros = c->d_zeros;
+    if (L.fc) { a.H = a.W = 1; a.in_stride = L.fc_h * L.fc_w * in.stride; }         // one "pixel" per image: the flattened producer
+    if (L.s2d7) { a.in = c->s2d.ptr; a.in_stride = 32; a.H = c->s2d.h; a.W = c->s2d.w; a.ksize = 4; a.stride = 1; a.pad = 2; }   // see pack_s2d7
     conv_finalize(a);
     return a;
 }
@@ -485,6 +534,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             break;
         }
         ConvArgs a = conv_args(c, L, n);
+        if (L.s2d7) HIPCK(c, launch_reorg(nview(c->input), nview(c->s2d), 2, 0, s));      // tf.space_to_depth order: (dy, dx, channel)
         if (L.halo) {          // small-Cin 3x3: input tile staged once in LDS (conv_stem.hip)
             HaloArgs h; memset(&h, 0, sizeof h);
             h.in = a.in; h.in_stride = a.in_stride; h.w = a.wt; h.b = a.bias; h.Kpad = a.Kpad; h.Cin = L.cin; h.Cout = L.filters; h.act = L.act;
@@ -524,6 +574,11 @@ int run_layer(yolo_ctx *c, int i, int n)
     case L_UPSAMPLE: HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
     case L_MAXPOOL: HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
     case L_REORG: HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
+    case L_DETECT: {
+        const Layer &P = c->layers[i - 1];
+        HIPCK(c, launch_decode_v1((const float *)P.out.ptr, P.out.stride, n, L.side, L.na, L.classes, L.sqr, c->d_det, c->rows, L.row_off,
+                                  c->d_scores, c->d_labels, s));
+        break; }
     case L_YOLO: case L_REGION: {
         DecodeArgs d; memset(&d, 0, sizeof d);
         const Layer &P = c->layers[i - 1];
@@ -549,7 +604,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
         HIPCK(c, hipMemcpyAsync(c->d_stage, images, npix * 3 * (fmt == YOLO_IMG_U8 ? 1 : 4), hipMemcpyHostToDevice, c->stream));
         src = c->d_stage;
     }
-    HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream));
+    HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream, c->in_mul, c->in_add));
     return YOLO_OK;
 }
 
@@ -572,7 +627,7 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
          int nms_mode, int select_mode, int img_h, int img_w, int scores_ready, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
 {
     if (max_out < 1) return fail(c, YOLO_ERR_INVALID, "max_out < 1");
-    if (nms_mode < 0 || nms_mode > 3 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
+    if (nms_mode < 0 || nms_mode > 4 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
     size_t need = (size_t)n * max_out;
     if ((int)need > c->boxes_cap) {
         // a captured detect graph holds the old pointer (memset, NMS writes, D2D copy): it must not be replayed
@@ -720,7 +775,7 @@ void yolo_destroy(yolo_ctx *c)
     for (void *p : c->phys) if (p) hipFree(p);
     for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
-                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4};
+                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -762,7 +817,29 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
             channel_scales(c, L.in[0], in_sc);
             if ((int)in_sc.size() != L.cin) return fail(c, YOLO_ERR_STATE, "internal: scale vector of %zu for %d channels", in_sc.size(), L.cin);
         }
-        pack_conv(L, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics);
+        std::vector<float> wperm;
+        const Layer *PL = &L; Layer tmp;
+        if (L.fc && L.fc_h * L.fc_w > 1) {
+            // darknet / the transposed TF graph flatten the producer CHW (V1/YOLO_V1_Inference.py:196-198); the tensor here is HWC
+            const int hw = L.fc_h * L.fc_w, C = L.fc_c;
+            wperm.resize((size_t)L.filters * L.cin);
+            for (int o = 0; o < L.filters; ++o)
+                for (int ch = 0; ch < C; ++ch)
+                    for (int q = 0; q < hw; ++q) wperm[(size_t)o * L.cin + (size_t)q * C + ch] = w[(size_t)o * L.cin + (size_t)ch * hw + q];
+            w = wperm.data();
+        } else if (L.s2d7) {
+            // 7x7 / stride 2 / pad 3 over 3 channels == 4x4 / stride 1 / pad 2 over the 2x2 space-to-depth image (32 = 4 positions x 8 padded
+            // channels): input row 2*oy + kh - 3 = 2*(oy + a - 2) + dy  <=>  kh = 2a + dy - 1 (taps outside 0..6 get zero weights)
+            tmp = L; tmp.size = 4; tmp.cin = 32; PL = &tmp;
+            wperm.assign((size_t)L.filters * 32 * 16, 0.f);
+            for (int o = 0; o < L.filters; ++o)
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int a4 = 0; a4 < 4; ++a4) for (int dy = 0; dy < 2; ++dy) { const int kh = 2 * a4 + dy - 1; if (kh < 0 || kh > 6) continue;
+                        for (int b4 = 0; b4 < 4; ++b4) for (int dx = 0; dx < 2; ++dx) { const int kw = 2 * b4 + dx - 1; if (kw < 0 || kw > 6) continue;
+                            wperm[(((size_t)o * 32 + (dy * 2 + dx) * 8 + ch) * 4 + a4) * 4 + b4] = w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw]; } }
+            w = wperm.data();
+        }
+        pack_conv(*PL, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics);
         HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));
@@ -892,9 +969,9 @@ int yolo_head_geometry(const yolo_ctx *c, int head, int *kind, int *grid, int *a
     if (!c || head < 0) return YOLO_ERR_INVALID;
     int k = 0;
     for (auto &L : c->layers) {
-        if (L.type != L_YOLO && L.type != L_REGION) continue;
+        if (L.type != L_YOLO && L.type != L_REGION && L.type != L_DETECT) continue;
         if (k++ != head) continue;
-        if (kind) *kind = L.type == L_REGION ? 1 : 0;
+        if (kind) *kind = L.type == L_REGION ? 1 : L.type == L_DETECT ? 2 : 0;
         if (grid) *grid = L.H;
         if (anchors) *anchors = L.na;
         if (row_offset) *row_offset = L.row_off;
@@ -946,7 +1023,7 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
         HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3));
         HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
     }
-    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream);
+    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -1042,6 +1119,7 @@ int yolo_darknet_boxes(yolo_ctx *c, int w, int h, float thresh, int relative, fl
     DnBoxesArgs a; memset(&a, 0, sizeof a);
     a.det = c->d_det; a.attrs = c->attrs;
     for (auto &L : c->layers) {
+        if (L.type == L_DETECT) return fail(c, YOLO_ERR_UNSUPPORTED, "[detection] heads are not served through the darknet veneer");
         if (L.type != L_YOLO && L.type != L_REGION) continue;
         if (a.nheads == 8) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 8 heads");
         a.kind[a.nheads] = L.type == L_REGION; a.grid[a.nheads] = L.H; a.na[a.nheads] = L.na; a.off[a.nheads] = L.row_off; ++a.nheads;
@@ -1063,6 +1141,7 @@ size_t yolo_last_layer_size(const yolo_ctx *c)
     if (!c) return 0;
     for (int i = (int)c->layers.size() - 1; i >= 0; --i) {
         const Layer &L = c->layers[i];
+        if (L.type == L_DETECT) return 0;
         if (L.type == L_YOLO || L.type == L_REGION) return (size_t)L.H * L.W * L.na * (5 + L.classes);
     }
     return 0;

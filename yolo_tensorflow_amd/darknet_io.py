@@ -17,7 +17,7 @@ CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg")
 
 
 def cfg_text(name):
-    """Text of a shipped topology ('yolov3', 'yolov3-608', 'yolov3-tiny', 'yolov2', 'yolov2-tiny-voc')
+    """Text of a shipped topology ('yolov3', 'yolov3-608', 'yolov3-tiny', 'yolov2', 'yolov2-tiny-voc', 'yolov1')
     or of a cfg file path."""
     path = name if os.path.exists(name) else os.path.join(CFG_DIR, name + ".cfg")
     with open(path) as f:
@@ -72,22 +72,30 @@ def layer_shapes(secs):
             ls = [l if l >= 0 else i + l for l in ls]
             H, W = shapes[ls[0]][1], shapes[ls[0]][2]
             C = sum(shapes[l][3] for l in ls)
-        elif t not in ("shortcut", "yolo", "region"):
+        elif t == "connected":               # flattens its producer (CHW order, DN/connected_layer.c:151) to `output` values
+            cin = H * W * C
+            H, W, C = 1, 1, int(s["output"])
+        elif t == "detection":
+            H = W = int(s.get("side", 7))
+        elif t not in ("shortcut", "yolo", "region", "dropout"):
             raise ValueError("unsupported layer type [%s]" % t)
         shapes.append((t, H, W, C, cin))
     return shapes
 
 
 def conv_specs(secs):
-    """Per conv in file order: dict(filters, size, cin, bn, head)."""
+    """Per parameterised layer in file order ([convolutional], and [connected] as a 1x1 conv over the flattened producer):
+    dict(filters, size, cin, bn, head, index)."""
     shapes = layer_shapes(secs)
     layers = secs[1:]
     out = []
     for i, s in enumerate(layers):
+        head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region", "detection")
         if s["type"] == "convolutional":
-            head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
             out.append(dict(filters=int(s["filters"]), size=int(s["size"]), cin=shapes[i][4],
                             bn=int(s.get("batch_normalize", 0)), head=head, index=i))
+        elif s["type"] == "connected":
+            out.append(dict(filters=int(s["output"]), size=1, cin=shapes[i][4], bn=0, head=head, index=i))
     return out
 
 
@@ -163,6 +171,19 @@ def synth_weights(secs, seed=0, obj_bias=-0.75):
                 parts.append(b)
                 parts.append(rng.normal(0, np.sqrt(1.0 / (k * k * cin * max(cur, 1e-6))), n * cin * k * k))
                 cur = 1.0 + 1.0
+        elif t == "connected":
+            n, cin = int(s["output"]), shapes[i][4]
+            if i + 1 < len(layers) and layers[i + 1]["type"] == "detection":
+                # a [detection] head reads its inputs as probabilities / box numbers directly (no sigmoid): small filters around biases
+                # that look like them -- classes U(0,.9), confidences U(.05,.95), centres U(.1,.9), sqrt-sizes U(.3,.8)
+                h = layers[i + 1]; S, B, C = int(h.get("side", 7)), int(h.get("num", 1)), int(h.get("classes", 1))
+                b = np.concatenate([rng.uniform(0, .9, S * S * C), rng.uniform(.05, .95, S * S * B),
+                                    np.stack([rng.uniform(.1, .9, S * S * B), rng.uniform(.1, .9, S * S * B),
+                                              rng.uniform(.3, .8, S * S * B), rng.uniform(.3, .8, S * S * B)], -1).reshape(-1)])
+                parts += [b, rng.normal(0, 0.05 * np.sqrt(1.0 / (cin * max(cur, 1e-6))), n * cin)]
+            else:
+                parts += [rng.normal(0, .1, n), rng.normal(0, np.sqrt(2.0 / (cin * max(cur, 1e-6))), n * cin)]
+            cur = 1.0 + 0.01 if s.get("activation", "logistic") != "leaky" else 1.01
         elif t == "shortcut":
             f = int(s["from"]); f = f if f >= 0 else i + f
             # leaky outputs have a positive mean, so residual branches add coherently: use the fully
@@ -180,3 +201,9 @@ def synth_weights(secs, seed=0, obj_bias=-0.75):
 def default_header(secs):
     """(major, minor) the reference's files carry: v3 family -> (0,2) 64-bit seen; region (v2) -> (0,1)."""
     return (0, 2) if any(s["type"] == "yolo" for s in secs) else (0, 1)
+
+
+def v1_classes():
+    """Pascal VOC class names in the order of V1/YOLO_V1_Inference.py:40-44."""
+    return ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog", "horse",
+            "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]

@@ -17,7 +17,7 @@ SEM_TF, SEM_DARKNET = 0, 1
 DECODE_RATIO, DECODE_PIXEL = 0, 1
 HOST, DEVICE = 0, 1
 IMG_U8, IMG_F32, IMG_F32_CHW = 0, 1, 2
-NMS_TF, NMS_PER_CLASS, NMS_DARKNET, NMS_NUMPY_V3 = 0, 1, 2, 3
+NMS_TF, NMS_PER_CLASS, NMS_DARKNET, NMS_NUMPY_V3, NMS_TF_V1 = 0, 1, 2, 3, 4
 SELECT_GT, SELECT_GE = 0, 1
 
 BOX_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("score", "<f4"), ("cls", "<i4")])
