@@ -14,10 +14,10 @@ bool conv_halo13_ok(const ConvArgs &a)
     return (double)a.N * a.H * a.W * a.in_stride * dt_size(a.in_dt) < 2147483648.0;
 }
 
-template <int WC, int TC, int NL, int EB, bool FREE = false>
+template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2>
 static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
 {
-    constexpr int WP = 1, TP = 11, NS = 2, BK = 64, BC = WC * TC * 16;
+    constexpr int WP = 1, TP = 11, BK = 64, BC = WC * TC * 16;
     const long blocks = (long)a.N * (a.H / HALO_B) * (a.W / HALO_B);
     const long tiles = blocks * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL, true>();
@@ -25,6 +25,19 @@ static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
     hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, a);
+    return hipGetLastError();
+}
+
+// stamped diagnostic build of the free-running 176x256 form (tools only): per-wave cycle sums of the issue / wait / MFMA phases
+hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s)
+{
+    if (!conv_halo13_ok(a) || a.in_dt != DT_BF16) return hipErrorInvalidValue;
+    constexpr int WC = 8, TC = 2, BC = WC * TC * 16;
+    const long tiles = (long)a.N * (a.H / HALO_B) * (a.W / HALO_B) * ((a.Cout + BC - 1) / BC);
+    constexpr size_t lds = conv_lds_bytes<1, WC, 11, TC, 2, 64, 0, true>();
+    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<1, WC, 11, TC, 2, 64, true, 0, true, 2, true, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv_igemm<1, WC, 11, TC, 2, 64, true, 0, true, 2, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * WC), lds, s, a);
     return hipGetLastError();
 }
 
@@ -40,6 +53,7 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
     case 40: return f8 ? launch_h<8, 2, 0, 1, true>(a, s) : launch_h<8, 2, 0, 2, true>(a, s);
     case 41: return f8 ? launch_h<8, 1, 0, 1, true>(a, s) : launch_h<8, 1, 0, 2, true>(a, s);
     case 42: return f8 ? launch_h<4, 2, 0, 1, true>(a, s) : launch_h<4, 2, 0, 2, true>(a, s);
+    case 43: return f8 ? launch_h<8, 1, 0, 1, true, 3>(a, s) : launch_h<8, 1, 0, 2, true, 3>(a, s);
     default: return hipErrorInvalidValue;
     }
 }

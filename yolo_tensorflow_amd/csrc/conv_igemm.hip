@@ -186,7 +186,8 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
 // halo-staged 3x3 configurations (conv_halo13.hip; same columns): one 13x13 pixel block x (wc * tc * 16) channels per workgroup
 #define CONV_CFGS_HALO(X)                                                                              \
     X(36, 1, 8, 11, 2, 2, 64, 0) X(37, 1, 8, 11, 2, 2, 64, 4) X(38, 1, 4, 11, 2, 2, 64, 4) X(39, 1, 4, 11, 2, 2, 64, 0)   \
-    X(40, 1, 8, 11, 2, 2, 64, 0) X(41, 1, 8, 11, 1, 2, 64, 0) X(42, 1, 4, 11, 2, 2, 64, 0)        /* 40-42: free-running waves */
+    X(40, 1, 8, 11, 2, 2, 64, 0) X(41, 1, 8, 11, 1, 2, 64, 0) X(42, 1, 4, 11, 2, 2, 64, 0)        /* 40-: free-running waves */ \
+    X(43, 1, 8, 11, 1, 3, 64, 0)
 
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl, halo; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 0},

@@ -81,6 +81,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
 bool conv_halo13_ok(const ConvArgs &a);
 bool conv_cfg_is_halo(int cfg);
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
+hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s);      // stamped free-running 176x256 build (tools only)
 bool conv_cfg_tail_ok(int cfg, int cout);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
@@ -137,6 +138,9 @@ struct DecodeArgs {
     int region;                         // 1: softmax/region head
     float *det; int rows_total; int row_off;   // det [n, rows_total, 5+classes]; nullptr: the decoded tensor is not materialised ...
     float *box4;                        // ... only (cx, cy, w, h) of every row, [n, rows_total, 4] (yolo heads, with scores/labels)
+    float reject_below;                 // lean form: a box whose objectness is below this cannot reach the caller's score threshold
+                                        // (score = objectness * class probability <= objectness): its class work is skipped and its
+                                        // score is reported as the objectness itself.  -inf: every box is scored
 };
 // scores/labels (nullable): per-row max_k(obj*cls_k) and its first argmax, written alongside the decode
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s);

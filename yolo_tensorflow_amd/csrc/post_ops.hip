@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256) void k_decode_yolo_cell(const DecodeArgs a, fl
 #pragma unroll
             for (int r = 1; r < R; ++r) ov = orr == r ? v[r] : ov;
             const float obj = __shfl(ov, ol);
+            if (obj < a.reject_below) {                  // wave-uniform: cannot pass the threshold whatever its classes say
+                if (lane == 0) { scores[row0 + an] = obj; labels[row0 + an] = 0; }
+                continue;
+            }
             float sc[R]; float best = -INFINITY;
 #pragma unroll
             for (int r = 0; r < R; ++r) {

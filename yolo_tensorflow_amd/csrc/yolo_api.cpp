@@ -86,7 +86,7 @@ struct yolo_ctx {
     float in_mul = 1.f, in_add = 0.f;     // input normalisation after the /255: v * in_mul + in_add ([net] yolo_input_mul / yolo_input_add)
     float *d_det = nullptr; int rows = 0, attrs = 0;
     // lean detect path (yolo_detect*): the decode writes scores, labels and the four box numbers of every row, not the tensor
-    float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false;
+    float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false; float lean_thr = 0.f;
     // postprocess workspace
     float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
@@ -588,6 +588,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         for (int k = 0; k < 2 * L.na; ++k)
             d.anchors[k] = L.type == L_YOLO ? (float)(1.0 * (double)L.anchors[k] / (double)stride) : L.anchors[k];
         d.det = c->lean ? nullptr : c->d_det; d.box4 = c->lean ? c->d_box4 : nullptr; d.rows_total = c->rows; d.row_off = L.row_off;
+        d.reject_below = c->lean ? c->lean_thr : -INFINITY;
         HIPCK(c, launch_decode(d, c->d_scores, c->d_labels, s));
         break; }
     }
@@ -995,9 +996,10 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
 }
 
 // lean: the caller goes straight on to threshold + NMS (yolo_detect*): the decoded tensor is not written, see yolo_ctx::lean
-static int forward_impl(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc, bool lean)
+static int forward_impl(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float *det_out, int out_loc, bool lean, float score_thr = 0.f)
 {
     if (!c) return YOLO_ERR_INVALID;
+    c->lean_thr = score_thr;
     if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "yolo_forward before weights were loaded");
     if (fmt != YOLO_IMG_U8 && fmt != YOLO_IMG_F32 && fmt != YOLO_IMG_F32_CHW) return fail(c, YOLO_ERR_INVALID, "bad image format");
     HIPCK(c, hipSetDevice(c->device));
@@ -1057,6 +1059,8 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
     if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "postprocess of %d images but the last forward ran %d", n, c->last_n);
     HIPCK(c, hipSetDevice(c->device));
     const int want = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
+    if (!c->det_valid && score_thr < c->lean_thr)
+        return fail(c, YOLO_ERR_STATE, "the last forward ran through yolo_detect* with score threshold %g and pruned the scores below it; a lower threshold needs yolo_forward", c->lean_thr);
     if (!c->det_valid && want != c->scores_mode)
         return fail(c, YOLO_ERR_STATE, "the last forward ran through yolo_detect* without materialising the decoded tensor; this NMS flavour needs it (call yolo_forward)");
     const int ready = c->scores_mode == want;
@@ -1068,7 +1072,7 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
 int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float score_thr, float iou_thr,
                 int max_out, int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
 {
-    int r = forward_impl(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3); if (r) return r;
+    int r = forward_impl(c, images, n, fmt, loc, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3, score_thr); if (r) return r;
     return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, out_loc);
 }
 
@@ -1083,7 +1087,7 @@ int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float sca
         c->gkey = k; if (c->gstate >= 0) c->gstate = 0;
     }
     auto eager = [&]() -> int {
-        int r = forward_impl(c, images, n, fmt, YOLO_DEVICE, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3); if (r) return r;
+        int r = forward_impl(c, images, n, fmt, YOLO_DEVICE, scale, nullptr, YOLO_DEVICE, nms_mode != YOLO_NMS_NUMPY_V3, score_thr); if (r) return r;
         return yolo_postprocess(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, YOLO_DEVICE);
     };
     if (c->gstate <= 0) { int r = eager(); if (r == YOLO_OK && c->gstate == 0) c->gstate = 1; return r; }
@@ -1442,11 +1446,14 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     if (conv_cfg_is_halo(tile_cfg) && (f32 || !conv_halo13_ok(a))) { g_op_err = "conv2d: tile config not applicable to this shape (halo-staged form: 3x3, stride 1, size a multiple of 13, whole channel chunks)"; return YOLO_ERR_UNSUPPORTED; }
     hipError_t e;
     if (dt != DT_F32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
-        // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build, printed to stderr
-        const long tiles = (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
-        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * 4 * 6 * 8);
-        for (int rep = 0; rep < 200; ++rep) e = launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
-        std::vector<unsigned long long> hd((size_t)tiles * 4 * 6);
+        // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build (YOLO_CONV_DIAG=free: of the free-running halo form
+        // f176c256), printed to stderr
+        const bool dfree = !strcmp(getenv("YOLO_CONV_DIAG"), "free") && conv_halo13_ok(a) && dt == DT_BF16;
+        const int wv = dfree ? 8 : 4;
+        const long tiles = dfree ? (long)n * (h / 13) * (w / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
+        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 6 * 8);
+        for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
+        std::vector<unsigned long long> hd((size_t)tiles * wv * 6);
         S.download(hd.data(), a.dbg, hd.size() * 8);
         double w = 0, is = 0, mm = 0, lp = 0, ep = 0, mhz = 0; size_t cnt = hd.size() / 6;
         const unsigned long long kt = hd[5] >> 40;
@@ -1521,7 +1528,7 @@ int yolo_op_decode(const float *raw, int n, int g, int na, int classes, const fl
     d.raw = d_r; d.raw_stride = na * attrs; d.n = n; d.g = g; d.na = na; d.classes = classes; d.img_size = img_size; d.mode = decode; d.region = region;
     const int stride = img_size / g;
     for (int k = 0; k < 2 * na; ++k) d.anchors[k] = region ? anchors_wh[k] : (float)(1.0 * (double)anchors_wh[k] / (double)stride);
-    d.det = d_o; d.rows_total = g * g * na; d.row_off = 0;
+    d.det = d_o; d.rows_total = g * g * na; d.row_off = 0; d.reject_below = -INFINITY;
     if (!S.ok(launch_decode(d, nullptr, nullptr, S.s))) { g_op_err = S.err; return S.rc; }
     return S.download(out, d_o, cnt * 4);
 }
