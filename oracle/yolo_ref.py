@@ -87,7 +87,7 @@ def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=Non
             p = params[ci]; ci += 1
             st = int(s.get("stride", 1))
             is_head = i + 1 < NL and layers[i + 1]["type"] in ("yolo", "region")
-            w, b = fold_bn(p)
+            w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
             if i == 0:
                 y = conv2d_nhwc(x, to_bf16(w), st) + b
             else:
@@ -267,12 +267,16 @@ def unflatten_weights(flat, secs):
     return out
 
 
-def fold_bn(p, eps=BN_EPS_TF):
+def fold_bn(p, eps=BN_EPS_TF, mode="tf"):
     """W' = W*gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps)  (SURVEY 8a row C).
-    fp32 arithmetic -- this is the load-time transformation the product applies."""
+    fp32 arithmetic -- this is the load-time transformation the product applies.  mode 'darknet': the scale of the reference's CPU
+    normalize, gamma / (sqrt(var) + 1e-6) (DN/blas.c:147-158), which the product uses under its darknet semantics."""
     if "bias" in p:
         return p["w_hwio"].astype(np.float32), p["bias"].astype(np.float32)
-    s = (p["gamma"] / np.sqrt(p["var"] + np.float32(eps))).astype(np.float32)
+    if mode == "darknet":
+        s = (p["gamma"] / (np.sqrt(p["var"]) + np.float32(.000001))).astype(np.float32)
+    else:
+        s = (p["gamma"] / np.sqrt(p["var"] + np.float32(eps))).astype(np.float32)
     return (p["w_hwio"] * s[None, None, None, :]).astype(np.float32), \
            (p["beta"] - p["mean"] * s).astype(np.float32)
 
@@ -758,7 +762,7 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
             k, st = int(s["size"]), int(s.get("stride", 1))
             is_head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
             if emulate_bf16:
-                w, b = fold_bn(p)
+                w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
                 y = conv2d_nhwc(x, to_bf16(w), st) + b
             elif "bias" in p:
                 y = conv2d_nhwc(x, p["w_hwio"], st) + p["bias"]

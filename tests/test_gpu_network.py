@@ -347,3 +347,98 @@ def test_fused_1x1_tail_equals_separate_launch(hiplib, dtype_name):
         eng.detect_graph(dimg, boxes, counts, score_thr=0.3, iou_thr=0.5, max_out=20)
     eng.synchronize()
     eng.close()
+
+
+STEM_NET = """[net]
+width=416
+height=416
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+
+[maxpool]
+size=2
+stride=2
+
+[maxpool]
+size=2
+stride=2
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+filters=255
+size=1
+stride=1
+pad=1
+activation=linear
+
+[yolo]
+mask=0,1,2
+anchors=10,13, 16,30, 33,23
+classes=80
+num=3
+"""
+
+
+def test_stem_and_halo_kernels_at_full_size_vs_oracle(hiplib):
+    """The two special kernels of the first stage at their real geometry (416x416 in, 208x208 out, batch 2): conv_stem_c32_c64
+    (conv0 + conv1 + conv2 in one launch) and conv_halo_c32_c64 (conv3 + shortcut).  (a) every layer of the layer-by-layer
+    plan -- which runs conv3 through the halo kernel too -- against the oracle at the device's storage precision; (b) the production
+    plan (fused stem, nothing materialised) bit-identical to the layer-by-layer plan."""
+    secs = IO.parse_cfg(STEM_NET); flat = IO.synth_weights(secs, seed=6)
+    img = np.random.default_rng(8).integers(0, 256, (2, 416, 416, 3), dtype=np.uint8)
+    osecs = R.parse_cfg(STEM_NET); params = R.unflatten_weights(flat, osecs)
+    _, outs = R.forward(osecs, params, R.to_bf16(img.astype(np.float32) / np.float32(255)), emulate_bf16=True, collect=True)
+    full = hiplib.Engine(STEM_NET, max_batch=2, keep_layers=True)
+    full.set_weights(flat)
+    det_layers = full.forward(img)
+    for i in range(5):
+        got = full.layer_output(i, 2)
+        assert got.shape == outs[i].shape == (2, (416, 208, 208, 208, 208)[i], (416, 208, 208, 208, 208)[i], (32, 64, 32, 64, 64)[i])
+        err = np.abs(got - outs[i])
+        # one bf16 ulp of the value plus the ulp of the pre-rounding operands that flipped upstream
+        assert (err <= 2.0 ** -6 * np.abs(outs[i]) + 4e-2).all(), "layer %d: max err %.3e" % (i, err.max())
+        assert float(err.mean()) < 2e-3, "layer %d: mean err %.3e" % (i, err.mean())
+    full.close()
+    prod = hiplib.Engine(STEM_NET, max_batch=2)
+    prod.set_weights(flat)
+    det = prod.forward(img)
+    prod.close()
+    assert np.array_equal(det, det_layers)

@@ -53,6 +53,23 @@ def test_conv_bf16_all_yolov3_shapes(hiplib, shape):
     _assert_bf16_close(got, ref)
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 208, 64, 128), (1, 1, 104, 128, 64), (3, 1, 104, 64, 128), (3, 1, 208, 32, 64), (3, 2, 416, 32, 64)],
+                         ids=lambda s: "k%d_s%d_h%d_%dto%d" % s)
+def test_conv_bf16_early_layers_at_full_size(hiplib, shape):
+    """The large-spatial-extent layers of YOLOv3-416 at their REAL size (the 23-shape test above shrinks H to <= 26): 104x104 and
+    208x208 stages, one image, against the oracle; with the fused shortcut where the network has one."""
+    k, s, h, cin, cout = shape
+    rng = np.random.default_rng(h * 31 + cin)
+    x = R.to_bf16(rng.standard_normal((1, h, h, cin)).astype(np.float32))
+    w = R.to_bf16((rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = R.leaky_relu(R.conv2d_nhwc(x, w, s) + b)
+    _assert_bf16_close(hiplib.op_conv2d(x, w, b, stride=s, act=1), ref)
+    if k == 3 and s == 1:
+        res = R.to_bf16(rng.standard_normal(ref.shape).astype(np.float32))
+        _assert_bf16_close(hiplib.op_conv2d(x, w, b, stride=s, act=1, residual=res), R.to_bf16(ref) + res, scale=np.abs(ref) + np.abs(res))
+
+
 @pytest.mark.parametrize("shape", [(3, 1, 26, 64, 128), (1, 1, 13, 1024, 255), (3, 2, 26, 32, 64), (3, 1, 20, 3, 32)],
                          ids=lambda s: "k%d_s%d_h%d_%dto%d" % s)
 def test_conv_bf16_every_tile_config_agrees(hiplib, shape):
