@@ -3,7 +3,7 @@
 # the PMC passes (HBM traffic, MFMA busy) on tools/prof_forward.py.  Everything lands in gpurun_out/prof_$1/;
 # tools/summarize_profile.py condenses that into $OUT/summary/, which is copied to profiles/ by hand afterwards.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/prof_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
