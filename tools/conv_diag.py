@@ -11,4 +11,4 @@ for mode in ("1", "free"):
         x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
         w = (rng.standard_normal((k, k, cin, cout)) * 0.05).astype(np.float32)
         print("mode", mode, "shape", (n, h, cin, cout, k), file=sys.stderr, flush=True)
-        hip.op_conv2d(x, w, None, act=1, dtype={"bf16": hip.BF16, "fp8": hip.FP8}[os.environ.get("DTYPE", "bf16")])
+        hip.op_conv2d(x, w, None, act=1, residual=rng.standard_normal((n, h, h, cout)).astype(np.float32), dtype={"bf16": hip.BF16, "fp8": hip.FP8}[os.environ.get("DTYPE", "bf16")])

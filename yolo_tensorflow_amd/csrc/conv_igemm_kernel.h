@@ -16,6 +16,16 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rn(float f)
     return (uint32_t)__builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// two floats -> packed bf16 pair (lo | hi << 16) in ONE v_cvt_pk_bf16_f32 (same RNE as f32_to_bf16_rn)
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+// max(a, b) for finite operands without the sNaN-quieting v_max the compiler puts in front of fmaxf (one instruction, not two)
+__device__ __forceinline__ float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // two floats -> two OCP e4m3 codes (RNE, saturating at +-448) merged into the low / high half of `old`
 template <bool HI> __device__ __forceinline__ uint32_t f32x2_to_fp8(float a, float b, uint32_t old)
 {
@@ -98,6 +108,9 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // 8 groups instead of 4 -- +-1 %; a direct-store epilogue (v_permlane32_swap pairs, 16-B stores straight from the accumulators, no
 // LDS staging and no barrier) -- bit-identical and not one microsecond faster: the ~10 us a layer pays outside its K loop are the
 // dispatch and the prologue / epilogue HBM bursts of 256 workgroups that are all in the same phase, not the staging.)
+// (Tried and dropped: starting half of the workgroups 3-6 us late -- by XCD parity, by CU parity inside an XCD, in four phases -- so
+// that the prologue / epilogue bursts of the two halves do not coincide.  The late half costs its full delay on every layer (26x26:
+// +2.2 us per 3 us of delay) and the early half gains < 1 us: the fixed phases are latency chains per CU, not an aggregate HBM limit.)
 template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
@@ -135,6 +148,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][ BP rows | BC rows ][128 B]
 
+    unsigned long long t_top = 0;              // DIAG: first instruction of the wave
+    if (DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_top)::"memory");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     }
     int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
     // DIAG (separate diagnostic instantiation, never the shipped kernel): s_memtime stamps around the phases of a K-step
-    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0;
+    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0, t_first = 0, te1 = 0, te2 = 0, te3 = 0;
     auto stamp = [&]() -> unsigned long long {
         unsigned long long t = 0;
         if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
@@ -440,6 +455,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         if (is_loader) { if (LOAD) wait_vmcnt<(D - 1) * L>(); else wait_vmcnt<0>(); }
         block_barrier();                       // everybody's part of K-step kt is in LDS; stage `nxt` is free again
         const unsigned long long s1 = stamp();
+        if (DIAG && !t_first) t_first = s1;
         if (LOAD && is_loader) stage(fill);
         const unsigned long long s2 = stamp();
         __builtin_amdgcn_s_setprio(2);          // MFMA phase: win issue arbitration against the co-resident workgroup's DMA / epilogue phases
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             s1 = stamp();
             issue();
             s2 = stamp();
-            if (DIAG) { t_wait += s1 - s0; t_issue += s2 - s1; }
+            if (DIAG) { t_wait += s1 - s0; t_issue += s2 - s1; if (!t_first) t_first = s1; }
         } else {
             issue();
             s1 = stamp();
@@ -564,13 +580,33 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (DIAG) t_loop_end = stamp();
 
     // ---- epilogue ----
-    const bool full = !HALO && (pt * BP + BP <= M) && (ct * BC + BC <= a.Cout);     // no ragged edge in this tile
-    // flat output pixel index of row `row` of this workgroup's tile (M, which is never stored, for a padding row of the halo form)
-    auto row_m = [&](int row) -> int {
+    // bf16 / fp8 stores and shortcut loads go through buffer descriptors based at this workgroup's first pixel and channel: the lane
+    // offset is 32-bit (pixel index relative to the tile origin x pixel stride, one 24-bit multiply) and a row or channel that is not
+    // stored gets an out-of-range offset (loads return zero, stores are dropped) -- no 64-bit address arithmetic, no exec-mask
+    // branches.  The epilogue is VALU-issue-bound (two waves per SIMD, ~4 cycles per instruction each): instruction count is its cost.
+    const size_t m0 = HALO ? ((size_t)(bn * a.H + by * HB) * a.W + bx * HB) : (size_t)pt * BP;      // tile origin (flat pixel index)
+    const int rows_left = HALO ? BP : (int)((size_t)M - m0 < (size_t)BP ? (size_t)M - m0 : (size_t)BP);    // tiled form: rows of the tile inside the tensor
+    // descriptor based at `p` (a wave-uniform address; the read-first-lane pins it to SGPRs, otherwise every access is wrapped in a
+    // waterfall loop)
+    auto tile_rsrc = [&](const void *p) -> __amdgpu_buffer_rsrc_t {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, BUF_RECORDS, 0x00020000);
+    };
+    // byte offset (from the tile origin, channel tile ct) of 16-byte piece c of the tile -- row-major, `cpr` pieces of `cpp` channels
+    // per row, pixel stride `sb` bytes -- or OOB_OFFSET when the piece is not stored; also returns the piece's row and position
+    auto piece_off = [&](int c, int cpr, int cpp, unsigned sb, int &row, int &cc) -> unsigned {
+        row = c / cpr; cc = c - row * cpr;
+        unsigned rel; bool ok;
         if constexpr (HALO) {
-            const int y = row / HB, x = row - y * HB;
-            return row < HB * HB ? (bn * a.H + by * HB + y) * a.W + bx * HB + x : M;
-        } else return pt * BP + row;
+            static_assert(HB == 13 && BP < 350, "row / 13 as (row * 79) >> 10");
+            const unsigned y = __umul24((unsigned)row, 79u) >> 10, x = (unsigned)row - __umul24(y, 13u);
+            rel = __umul24(y, (unsigned)a.W) + x; ok = row < HB * HB;
+        }
+        else { rel = (unsigned)row; ok = row < rows_left; }
+        ok = ok && ct * BC + cc * cpp < a.Cout;
+        const unsigned off = __umul24(rel, sb) + (unsigned)cc * 16u;
+        return ok ? off : OOB_OFFSET;
     };
     if (a.out_dt != DT_F32) {
         // bf16 / fp8 output: scale + bias + activation in registers, then the tile goes through LDS (as bf16) so that
@@ -582,28 +618,26 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         constexpr int CPR = BC / 8, NIT = (BP * CPR + NT - 1) / NT;       // bf16 pieces per row / per thread
         constexpr int CPR8 = BC / 16, NIT8 = (BP * CPR8 + NT - 1) / NT;   // fp8 pieces
         const bool out8 = a.out_dt == DT_FP8;
+        const unsigned osz = out8 ? 1u : 2u;                  // bytes per stored element
+        const char *__restrict__ res = (const char *)a.res;
+        const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc((char *)a.out + (m0 * a.out_stride + (size_t)ct * BC) * osz);
+        const __amdgpu_buffer_rsrc_t rs_res = tile_rsrc(res ? res + (m0 * a.res_stride + (size_t)ct * BC) * osz : nullptr);
+        const unsigned out_sb = a.out_stride * osz, res_sb = a.res_stride * osz;       // pixel strides in bytes (< 2^24)
         // residual (shortcut source) pieces are fetched now, all at once, so that their latency is covered by the
         // accumulator -> LDS pass below instead of being paid once per piece in the store loop
-        const char *__restrict__ res = (const char *)a.res;
-        uint4 rpre[NIT];
+        u32x4_t rpre[NIT];
         if (res) {
             if (out8) {
 #pragma unroll
                 for (int it = 0; it < NIT8; ++it) {
-                    const int c = tid + it * NT;
-                    const int row = c / CPR8, cc = c - row * CPR8;
-                    const int m = row_m(row), ch = ct * BC + cc * 16;
-                    rpre[it] = (c < BP * CPR8 && m < M && ch < a.Cout) ? *(const uint4 *)(res + (size_t)m * a.res_stride + ch)
-                                                                       : uint4{0, 0, 0, 0};
+                    int row, cc;
+                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR8, 16, res_sb, row, cc), 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    const int c = tid + it * NT;
-                    const int row = c / CPR, cc = c - row * CPR;
-                    const int m = row_m(row), ch = ct * BC + cc * 8;
-                    rpre[it] = (c < BP * CPR && m < M && ch < a.Cout) ? *(const uint4 *)(res + ((size_t)m * a.res_stride + ch) * 2)
-                                                                      : uint4{0, 0, 0, 0};
+                    int row, cc;
+                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR, 8, res_sb, row, cc), 0, 0);
                 }
             }
         }
@@ -619,41 +653,43 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         int prow[HALO ? TP : 1];
         if constexpr (HALO) {
 #pragma unroll
-            for (int j = 0; j < TP; ++j) prow[j] = kHaloPerm13[j * 16 + l15] >> 8;
+            for (int j = 0; j < TP; ++j) prow[j] = (kHaloPerm13[j * 16 + l15] >> 8) * RS;      // byte offset of the row in the LDS tile
         }
         block_barrier();                                      // every wave is done reading the last stage
+        if (DIAG) te1 = stamp();
+        const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
         if (is_consumer)
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
-            const float4 bv = *(const float4 *)(a.bias + ct * BC + chl);
-            float4 sv = float4{1.f, 1.f, 1.f, 1.f};
-            if (EB == 1 && a.oscale) sv = *(const float4 *)(a.oscale + ct * BC + chl);
+            const f32x4 bv = *(const f32x4 *)(a.bias + ct * BC + chl);
+            f32x4 sv = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (EB == 1 && a.oscale) sv = *(const f32x4 *)(a.oscale + ct * BC + chl);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                float v[4];
-                if (EB == 1) { v[0] = acc[i][j][0] * sv.x + bv.x; v[1] = acc[i][j][1] * sv.y + bv.y; v[2] = acc[i][j][2] * sv.z + bv.z; v[3] = acc[i][j][3] * sv.w + bv.w; }
-                else { v[0] = acc[i][j][0] + bv.x; v[1] = acc[i][j][1] + bv.y; v[2] = acc[i][j][2] + bv.z; v[3] = acc[i][j][3] + bv.w; }
-                if (a.act == ACT_LEAKY) {
+                f32x4 v = acc[i][j];
+                if (EB == 1) v = v * sv;
+                v = v + bv;
+                const f32x4 t = v * slope;                    // leaky: max(v, 0.1 v) == v > 0 ? v : 0.1 v; linear: max(v, v)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
-                }
+                for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], t[q]);
                 uint2 pk;
-                pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
-                pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
-                *(uint2 *)(smem + (HALO ? prow[j] : (wpi * TP + j) * 16 + l15) * RS + chl * 2) = pk;
+                pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                *(uint2 *)(smem + (HALO ? prow[j] : ((wpi * TP + j) * 16 + l15) * RS) + chl * 2) = pk;
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (one straight-line block of TC * TP sub-tiles otherwise)
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();
+        if (DIAG) te2 = stamp();
         if (out8) {
             // e4m3 output: the bf16-rounded value times 1/scale, RNE, saturating (shortcut: see below)
 #pragma unroll
             for (int it = 0; it < NIT8; ++it) {
-                const int c = tid + it * NT;
-                const int row = c / CPR8, cc = c - row * CPR8;
-                const int m = row_m(row), ch = ct * BC + cc * 16;
-                if (c >= BP * CPR8 || (!full && (m >= M || ch >= a.Cout))) continue;
+                int row, cc;
+                const unsigned off = piece_off(tid + it * NT, CPR8, 16, out_sb, row, cc);
+                if (off == OOB_OFFSET) continue;
                 const uint4 o0 = *(const uint4 *)(smem + row * RS + cc * 32), o1 = *(const uint4 *)(smem + row * RS + cc * 32 + 16);
                 const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
                 float v[16];
@@ -662,8 +698,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 if (res) {
                     // as if the shortcut ran as its own kernel (ew_ops k_add): this conv's output is first quantised
                     // with its own scale, then (x * s_x + r * s_r) is formed with separately rounded operations
-                    const uint4 r = rpre[it];
-                    const int rw[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+                    const u32x4_t r = rpre[it];
+                    const int rw[4] = {(int)r[0], (int)r[1], (int)r[2], (int)r[3]};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int xw = (int)f32x2_to_fp8<true>(v[4 * q + 2] * a.mid_inv_scale, v[4 * q + 3] * a.mid_inv_scale,
@@ -679,7 +715,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int q = 0; q < 4; ++q)
                     pw[q] = f32x2_to_fp8<true>(v[4 * q + 2] * a.out_inv_scale, v[4 * q + 3] * a.out_inv_scale,
                                                f32x2_to_fp8<false>(v[4 * q] * a.out_inv_scale, v[4 * q + 1] * a.out_inv_scale, 0));
-                *(uint4 *)((char *)a.out + (size_t)m * a.out_stride + ch) = uint4{pw[0], pw[1], pw[2], pw[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pw[0], pw[1], pw[2], pw[3]}, rs_out, off, 0, 0);
                 if (TAIL_OK && EB == 1) if (a.w2) *(uint4 *)(smem + BP * RS + row * (BC + 16) + cc * 16) = uint4{pw[0], pw[1], pw[2], pw[3]};
             }
             if constexpr (TAIL_OK && EB == 1) if (a.w2) {
@@ -727,36 +763,36 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 block_barrier();
                 constexpr int CPR2 = C2 / 16;
-                for (int c = tid; c < BP * CPR2; c += NT) {
-                    const int row = c / CPR2, cc = c - row * CPR2;
-                    const int m = row_m(row);
-                    if (m < M) *(uint4 *)((char *)a.out2 + (size_t)m * a.out2_stride + cc * 16) = *(const uint4 *)(st2 + row * RS2 + cc * 16);
+                const __amdgpu_buffer_rsrc_t rs_out2 = tile_rsrc((char *)a.out2 + m0 * a.out2_stride);
+#pragma unroll
+                for (int it = 0; it < (BP * CPR2 + NT - 1) / NT; ++it) {
+                    int row, cc;
+                    const unsigned off = piece_off(tid + it * NT, CPR2, 0, (unsigned)a.out2_stride, row, cc);
+                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, 0);
                 }
             }
         } else {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int c = tid + it * NT;
-                const int row = c / CPR, cc = c - row * CPR;
-                const int m = row_m(row), ch = ct * BC + cc * 8;
-                if (c >= BP * CPR || (!full && (m >= M || ch >= a.Cout))) continue;
-                uint4 o = *(const uint4 *)(smem + row * RS + cc * 16);
+                int row, cc;
+                const unsigned off = piece_off(tid + it * NT, CPR, 8, out_sb, row, cc);
+                if ((BP * CPR) % NT != 0 && tid + it * NT >= BP * CPR) continue;       // (only shapes whose piece count is ragged)
+                u32x4_t o = *(const u32x4_t *)(smem + row * RS + cc * 16);
                 if (res) {
                     // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
                     // by a separate shortcut kernel; the sum is rounded once more
-                    const uint4 r = rpre[it];
-                    uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
+                    const u32x4_t r = rpre[it];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float lo = bf16_bits_to_f32(ov[q] & 0xffff) + bf16_bits_to_f32(rv[q] & 0xffff);
-                        const float hi = bf16_bits_to_f32(ov[q] >> 16) + bf16_bits_to_f32(rv[q] >> 16);
-                        ov[q] = f32_to_bf16_rn(lo) | (f32_to_bf16_rn(hi) << 16);
+                        const float lo = __builtin_bit_cast(float, o[q] << 16) + __builtin_bit_cast(float, r[q] << 16);
+                        const float hi = __builtin_bit_cast(float, o[q] & 0xffff0000u) + __builtin_bit_cast(float, r[q] & 0xffff0000u);
+                        o[q] = f32x2_to_bf16x2(lo, hi);
                     }
-                    o = uint4{ov[0], ov[1], ov[2], ov[3]};
-                    if (TAIL_OK && EB == 2 && a.w2) *(uint4 *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
+                    if (TAIL_OK && EB == 2 && a.w2) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                 }
-                *(uint4 *)((bf16_t *)a.out + (size_t)m * a.out_stride + ch) = o;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
             }
+            if (DIAG) te3 = stamp();
             if constexpr (TAIL_OK && EB == 2) if (a.w2) {
                 // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.
                 //      Consumer wave w owns output channels 16w..16w+15 for every pixel of the tile; its filter fragments
@@ -810,10 +846,12 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 block_barrier();
                 constexpr int CPR2 = C2 / 8;
-                for (int c = tid; c < BP * CPR2; c += NT) {
-                    const int row = c / CPR2, cc = c - row * CPR2;
-                    const int m = row_m(row);
-                    if (m < M) *(uint4 *)((bf16_t *)a.out2 + (size_t)m * a.out2_stride + cc * 8) = *(const uint4 *)(st2 + row * RS2 + cc * 16);
+                const __amdgpu_buffer_rsrc_t rs_out2 = tile_rsrc((char *)a.out2 + m0 * a.out2_stride * 2);
+#pragma unroll
+                for (int it = 0; it < (BP * CPR2 + NT - 1) / NT; ++it) {
+                    int row, cc;
+                    const unsigned off = piece_off(tid + it * NT, CPR2, 0, (unsigned)a.out2_stride * 2u, row, cc);
+                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, 0);
                 }
             }
         }
@@ -847,9 +885,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (DIAG && a.dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = stamp();
-        unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 6;
+        unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 12;
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end;
+        d[6] = t_all0 - t_top; d[7] = t_first - t_all0; d[8] = te1 - t_loop_end; d[9] = te2 - te1; d[10] = te3 - te2; d[11] = t_end - te3;
         d[5] = ((unsigned long long)KT << 40) | ((t_end - t_all0) * 100ull / (rt1 - rt0 ? rt1 - rt0 : 1));   // KT | shader MHz (realtime = 100 MHz)
     }
 #endif

@@ -1451,15 +1451,19 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         const bool dfree = !strcmp(getenv("YOLO_CONV_DIAG"), "free") && conv_halo13_ok(a) && dt == DT_BF16;
         const int wv = dfree ? 8 : 4;
         const long tiles = dfree ? (long)n * (h / 13) * (w / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
-        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 6 * 8);
+        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 12 * 8);
         for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
-        std::vector<unsigned long long> hd((size_t)tiles * wv * 6);
+        std::vector<unsigned long long> hd((size_t)tiles * wv * 12);
         S.download(hd.data(), a.dbg, hd.size() * 8);
-        double w = 0, is = 0, mm = 0, lp = 0, ep = 0, mhz = 0; size_t cnt = hd.size() / 6;
+        double sum[12] = {0}; size_t cnt = hd.size() / 12;
         const unsigned long long kt = hd[5] >> 40;
-        for (size_t i = 0; i < cnt; ++i) { w += hd[i * 6]; is += hd[i * 6 + 1]; mm += hd[i * 6 + 2]; lp += hd[i * 6 + 3]; ep += hd[i * 6 + 4]; mhz += (double)(hd[i * 6 + 5] & 0xffffffffffull); }
+        for (size_t i = 0; i < cnt; ++i)
+            for (int q = 0; q < 12; ++q) sum[q] += q == 5 ? (double)(hd[i * 12 + 5] & 0xffffffffffull) : (double)hd[i * 12 + q];
+        for (double &v : sum) v /= cnt;
         fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz\n",
-                cnt, kt, w / cnt / kt, is / cnt / kt, mm / cnt / kt, lp / cnt / kt, ep / cnt, mhz / cnt);
+                cnt, kt, sum[0] / kt, sum[1] / kt, sum[2] / kt, sum[3] / kt, sum[4], sum[5]);
+        fprintf(stderr, "diag: setup (first instruction -> prologue issued) %.0f | first wait (prologue data + barrier) %.0f | epilogue: barrier %.0f  acc->LDS + barrier %.0f  shortcut add + store issue %.0f  store drain %.0f\n",
+                sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
     } else
         e = f32 ? launch_conv_f32(a, S.s)
                 : dt == DT_FP8 ? launch_conv_fp8(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s)
