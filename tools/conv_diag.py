@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from yolo_tensorflow_amd import hip
 rng = np.random.default_rng(0)
-for mode in ("1", "free"):
+for mode in os.environ.get("MODES", "1,free").split(","):
     os.environ["YOLO_CONV_DIAG"] = mode
     for (n, h, cin, cout, k) in ((32, 26, 256, 512, 3), (32, 52, 128, 256, 3), (32, 13, 512, 1024, 3)):
         x = rng.standard_normal((n, h, h, cin)).astype(np.float32)

@@ -28,8 +28,11 @@ def net(grid, cins, cout, cfg):
     return t, idx
 
 
-for grid, cins, cout, cfgs in ((26, (256, 512, 1024), 512, (40, 36, 16)), (52, (128, 256, 512), 256, (40, 36, 16)),
-                               (13, (512, 1024, 2048), 1024, (41, 43, 42, 23)), (104, (64, 128, 256), 128, (16, 41))):
+CASES = ((26, (256, 512, 1024), 512, (40, 36, 16)), (52, (128, 256, 512), 256, (40, 36, 16)),
+         (13, (512, 1024, 2048), 1024, (41, 43, 42, 23)), (104, (64, 128, 256), 128, (16, 41)))
+ONLY = [int(v) for v in os.environ.get("CFGS", "").split(",") if v]
+for grid, cins, cout, cfgs in CASES:
+    cfgs = [c for c in cfgs if not ONLY or c in ONLY]
     txt, idx = net(grid, cins, cout, cfgs)
     secs = IO.parse_cfg(txt)
     eng = hip.Engine(txt, max_batch=B); eng.set_weights(IO.synth_weights(secs, 0))

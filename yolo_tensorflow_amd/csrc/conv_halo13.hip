@@ -24,21 +24,28 @@ static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
     static_assert(lds <= 160 * 1024, "halo form: LDS");
     hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, HALO_B));
     return hipGetLastError();
 }
 
-// stamped diagnostic build of the free-running 176x256 form (tools only): per-wave cycle sums of the issue / wait / MFMA phases
-hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s)
+// stamped diagnostic builds of the free-running 176x256 form (tools only): per-wave cycle sums of the issue / wait / MFMA phases.
+// variant 1 (wide): four waves of 176 x 64 (one per SIMD) instead of eight of 176 x 32 -- what a K-step costs a wave that shares its SIMD with
+// nobody and reads 40 % fewer LDS bytes per FLOP
+template <int WC, int TC>
+static hipError_t launch_diag(const ConvArgs &a, hipStream_t s)
 {
-    if (!conv_halo13_ok(a) || a.in_dt != DT_BF16) return hipErrorInvalidValue;
-    constexpr int WC = 8, TC = 2, BC = WC * TC * 16;
+    constexpr int BC = WC * TC * 16;
     const long tiles = (long)a.N * (a.H / HALO_B) * (a.W / HALO_B) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<1, WC, 11, TC, 2, 64, 0, true>();
     hipError_t e = conv_opt_in_lds((const void *)conv_igemm<1, WC, 11, TC, 2, 64, true, 0, true, 2, true, true>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_igemm<1, WC, 11, TC, 2, 64, true, 0, true, 2, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * WC), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<1, WC, 11, TC, 2, 64, true, 0, true, 2, true, true>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * WC), lds, s, conv_tile_magic(a, BC, HALO_B));
     return hipGetLastError();
+}
+hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant)
+{
+    if (!conv_halo13_ok(a) || a.in_dt != DT_BF16) return hipErrorInvalidValue;
+    return variant == 1 ? launch_diag<4, 4>(a, s) : launch_diag<8, 2>(a, s);
 }
 
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)

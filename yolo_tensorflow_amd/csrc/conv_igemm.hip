@@ -54,7 +54,7 @@ static hipError_t launch_conv_diag_t(const ConvArgs &a, hipStream_t s)
     const long tiles = ((M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK>();
     { hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>, lds); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, 0, true, EB>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * NW), lds, s, conv_tile_magic(a, WC * TC * 16, 0));
     return hipGetLastError();
 }
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s) { return a.in_dt == DT_FP8 ? launch_conv_diag_t<1>(a, s) : launch_conv_diag_t<2>(a, s); }
@@ -236,7 +236,7 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
         hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>), grid, block, lds, s, conv_tile_magic(a, BC, 0));
     return hipGetLastError();
 }
 

@@ -111,6 +111,13 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // (Tried and dropped: starting half of the workgroups 3-6 us late -- by XCD parity, by CU parity inside an XCD, in four phases -- so
 // that the prologue / epilogue bursts of the two halves do not coincide.  The late half costs its full delay on every layer (26x26:
 // +2.2 us per 3 us of delay) and the early half gains < 1 us: the fixed phases are latency chains per CU, not an aggregate HBM limit.)
+// (Tried and dropped, round 2: software-pipelining the K-steps inside each wave -- next step's filter and first pixel fragments read
+// under the last MFMA groups, the DMA two steps ahead.  The wave's step then has no separate wait phase, but it got SLOWER, 1.10 vs
+// 1.03 us per K-step on the 26x26 layers: with both waves of a SIMD reading fragments all the time the LDS round trip grows to ~300
+// cycles and the four-deep read-ahead, not the start-up of a step, sets the pace (deeper read-ahead spills past 256 VGPRs).  A stamped
+// build with four waves of 176 x 64 -- one per SIMD, 40 % fewer LDS bytes per FLOP, nothing else on the SIMD -- needs 1708 cycles for
+// the 1408 cycles of MFMA of a K-step: the LDS array (213 KB of fragment reads plus 36 KB of DMA writes per K-step and CU) is the
+// resource this tiling runs out of, at about the rate measured now.)
 template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
@@ -170,12 +177,12 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= tilesP * tilesC) return;
-    const int ct = tile % tilesC;
-    const int pt = tile / tilesC;
+    const int pt = fast_div(tile, a.tc_mul, a.tc_shift);          // (scalar n / d by multiply-high: an s_ division is ~35 instructions)
+    const int ct = tile - pt * tilesC;
     int bn = 0, by = 0, bx = 0;                // halo form: image, block row, block column of this workgroup's 13x13 block
     if constexpr (HALO) {
         const int bpr = a.W / HB, bpi = bpr * (a.H / HB);
-        bn = pt / bpi; const int r = pt - bn * bpi; by = r / bpr; bx = r - by * bpr;
+        bn = fast_div(pt, a.bpi_mul, a.bpi_shift); const int r = pt - bn * bpi; by = fast_div(r, a.bpr_mul, a.bpr_shift); bx = r - by * bpr;
     }
 
     // Buffer descriptors.  The activation base is moved back by (W+1) pixels so that the offset of tap (0,0) of a
@@ -209,39 +216,50 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             aoff[i] = ok ? (unsigned)(((bn * a.H + iy) * a.W + ix) * a.in_stride * EB + c16 * 16) : OOB_OFFSET;
         }
     }
+    // The CPRW lanes that fill one LDS row all need the same (offset, tap mask) pair for each of the wave's LA row groups: lane q of
+    // such a lane group works out row group q (+ CPRW per pass) only, and the group exchanges the results with ds_bpermute -- one
+    // evaluation per lane instead of LA (this setup is ~55 instructions per row; it was a third of a short layer's fixed cost).
+    if constexpr (!HALO) {
+        const int q = lane % CPRW;
 #pragma unroll
-    for (int i = 0; i < (HALO ? 0 : LA); ++i) {
-        const int prow = (wid + i * NW) * RG + rl;
-        const int m = pt * BP + prow;
-        unsigned mask = 0, off = 0;
-        if (m < M && prow < BP) {
-            const int n = fast_div(m, a.howo_mul, a.howo_shift);
-            const int rem = m - n * HoWo;
-            const int oy = fast_div(rem, a.wo_mul, a.wo_shift);
-            const int ox = rem - oy * a.Wo;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride + (UNI ? chunk * EPC : 0)) * (unsigned)EB;
-            if (a.ksize == 3) {
-                unsigned ry = 0, cx = 0;
+        for (int p0 = 0; p0 < LA; p0 += CPRW) {
+            const int mine = p0 + q;                    // the row group this lane evaluates in this pass
+            const int prow = (wid + mine * NW) * RG + rl;
+            const int m = pt * BP + prow;
+            unsigned mask = 0, off = 0;
+            if (mine < LA && m < M && prow < BP) {
+                const int n = fast_div(m, a.howo_mul, a.howo_shift);
+                const int rem = m - n * HoWo;
+                const int oy = fast_div(rem, a.wo_mul, a.wo_shift);
+                const int ox = rem - oy * a.Wo;
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                off = (unsigned)(((n * a.H + iy0) * a.W + ix0 + a.W + 1) * a.in_stride) * (unsigned)EB;
+                if (a.ksize == 3) {
+                    unsigned ry = 0, cx = 0;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    ry |= ((unsigned)(iy0 + d) < (unsigned)a.H ? 1u : 0u) << d;
-                    cx |= ((unsigned)(ix0 + d) < (unsigned)a.W ? 1u : 0u) << d;
-                }
+                    for (int d = 0; d < 3; ++d) {
+                        ry |= ((unsigned)(iy0 + d) < (unsigned)a.H ? 1u : 0u) << d;
+                        cx |= ((unsigned)(ix0 + d) < (unsigned)a.W ? 1u : 0u) << d;
+                    }
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-                    if (ry & (1u << kh)) mask |= cx << (3 * kh);
-            } else if (a.ksize == 1) {
-                mask = ((unsigned)iy0 < (unsigned)a.H && (unsigned)ix0 < (unsigned)a.W) ? 1u : 0u;
-            } else {
-                for (int t = 0; t < KK; ++t) {
-                    const int kh = t / a.ksize, kw = t - kh * a.ksize;
-                    if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mask |= 1u << t;
+                    for (int kh = 0; kh < 3; ++kh)
+                        if (ry & (1u << kh)) mask |= cx << (3 * kh);
+                } else if (a.ksize == 1) {
+                    mask = ((unsigned)iy0 < (unsigned)a.H && (unsigned)ix0 < (unsigned)a.W) ? 1u : 0u;
+                } else {
+                    for (int t = 0; t < KK; ++t) {
+                        const int kh = t / a.ksize, kw = t - kh * a.ksize;
+                        if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mask |= 1u << t;
+                    }
                 }
             }
+#pragma unroll
+            for (int i = p0; i < LA && i < p0 + CPRW; ++i) {
+                const int src = ((lane & ~(CPRW - 1)) | (i - p0)) << 2;          // byte address of the source lane
+                rowoff[i] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)off) + (UNI ? (unsigned)(chunk * EPC * EB) : 0u);
+                tapmask[i] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)mask);
+            }
         }
-        rowoff[i] = off;
-        tapmask[i] = mask;
     }
     unsigned woff[LB > 0 ? LB : 1];
 #pragma unroll

@@ -49,22 +49,34 @@ struct ConvArgs {
     // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
     uint32_t howo_mul, howo_shift, wo_mul, wo_shift;
     unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
+    // division constants of the tile decode, filled by the launcher for its tile shape (conv_tile_magic): channel tiles per pixel
+    // tile; halo form: 13x13 blocks per image and per block row
+    uint32_t tc_mul, tc_shift, bpi_mul, bpi_shift, bpr_mul, bpr_shift;
 };
 // K-order chunk of a conv whose filters are stored with `wdt` elements: one 128-byte LDS row of channels when the padded
 // channel count is a multiple of that, else all channels (i.e. plain tap-major order); fp32 filters keep tap-major order
 inline int conv_kchunk(int cin_pad, int wdt) { const int row = wdt == DT_FP8 ? 128 : 64; return (wdt != DT_F32 && cin_pad % row == 0) ? row : cin_pad; }
 // host helper: derives the division constants from Ho, Wo (call after filling the geometry)
+inline void conv_magic(uint32_t d, uint32_t &mul, uint32_t &shift)
+{
+    if (d <= 1) { mul = 0; shift = 255; return; }
+    uint32_t l = 0; while ((1u << l) < d) ++l;          // ceil(log2 d)
+    const unsigned k = 31 + l;
+    mul = (uint32_t)(((unsigned long long)1 << k) / d + 1);
+    shift = k - 32;
+}
 inline void conv_finalize(ConvArgs &a)
 {
-    auto magic = [](uint32_t d, uint32_t &mul, uint32_t &shift) {
-        if (d <= 1) { mul = 0; shift = 255; return; }
-        uint32_t l = 0; while ((1u << l) < d) ++l;          // ceil(log2 d)
-        const unsigned k = 31 + l;
-        mul = (uint32_t)(((unsigned long long)1 << k) / d + 1);
-        shift = k - 32;
-    };
-    magic((uint32_t)(a.Ho * a.Wo), a.howo_mul, a.howo_shift);
-    magic((uint32_t)a.Wo, a.wo_mul, a.wo_shift);
+    conv_magic((uint32_t)(a.Ho * a.Wo), a.howo_mul, a.howo_shift);
+    conv_magic((uint32_t)a.Wo, a.wo_mul, a.wo_shift);
+}
+// launcher side of the tile decode: BC = output channels per workgroup, hb = block edge of the halo form (0: tiled form)
+inline ConvArgs conv_tile_magic(const ConvArgs &a0, int BC, int hb)
+{
+    ConvArgs a = a0;
+    conv_magic((uint32_t)((a.Cout + BC - 1) / BC), a.tc_mul, a.tc_shift);
+    if (hb > 0) { conv_magic((uint32_t)((a.H / hb) * (a.W / hb)), a.bpi_mul, a.bpi_shift); conv_magic((uint32_t)(a.W / hb), a.bpr_mul, a.bpr_shift); }
+    return a;
 }
 
 // opt a kernel in to more than 64 KiB of dynamic LDS, once per (device, kernel) -- the attribute is per device
@@ -81,7 +93,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
 bool conv_halo13_ok(const ConvArgs &a);
 bool conv_cfg_is_halo(int cfg);
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
-hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s);      // stamped free-running 176x256 build (tools only)
+hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant = 0);   // 0: eight waves of 176 x 32 (the shipped shape), 1: four waves of 176 x 64      // stamped free-running 176x256 build (tools only)
 bool conv_cfg_tail_ok(int cfg, int cout);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);

@@ -1448,11 +1448,12 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     if (dt != DT_F32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build (YOLO_CONV_DIAG=free: of the free-running halo form
         // f176c256), printed to stderr
-        const bool dfree = !strcmp(getenv("YOLO_CONV_DIAG"), "free") && conv_halo13_ok(a) && dt == DT_BF16;
-        const int wv = dfree ? 8 : 4;
+        const bool dwide = !strcmp(getenv("YOLO_CONV_DIAG"), "free4");        // four waves of 176 x 64
+        const bool dfree = (dwide || !strcmp(getenv("YOLO_CONV_DIAG"), "free")) && conv_halo13_ok(a) && dt == DT_BF16;
+        const int wv = dfree && !dwide ? 8 : 4;
         const long tiles = dfree ? (long)n * (h / 13) * (w / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
         a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 12 * 8);
-        for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
+        for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s, dwide ? 1 : 0) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
         std::vector<unsigned long long> hd((size_t)tiles * wv * 12);
         S.download(hd.data(), a.dbg, hd.size() * 8);
         double sum[12] = {0}; size_t cnt = hd.size() / 12;
