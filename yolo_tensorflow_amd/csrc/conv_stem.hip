@@ -24,10 +24,22 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t stem_bf16(float f)
+// Both kernels are VALU-issue-bound (two waves per SIMD, ~4 cycles per instruction): the epilogues are written for instruction count.
+typedef __bf16 st_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float st_f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (lo | hi << 16), one v_cvt_pk_bf16_f32 (RNE)
+__device__ __forceinline__ uint32_t stem_pk(float lo, float hi)
 {
-    __bf16 b = (__bf16)f;
-    return (uint32_t)__builtin_bit_cast(uint16_t, b);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_bf16x2));
+}
+// max for finite operands as ONE instruction (fmaxf is preceded by an sNaN-quieting v_max)
+__device__ __forceinline__ float stem_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// acc + bias, activation (slope 0.1: leaky as max(v, 0.1 v); slope 1: linear), rounded to bf16: four channels as two packed words
+__device__ __forceinline__ uint2 stem_epi(const f32x4 acc, const f32x4 bias, const float slope)
+{
+    f32x4 v = acc + bias;
+    const f32x4 t = v * slope;
+    return uint2{stem_pk(stem_max(v[0], t[0]), stem_max(v[1], t[1])), stem_pk(stem_max(v[2], t[2]), stem_max(v[3], t[3]))};
 }
 
 constexpr int ST_TH = 8, ST_TW = 16;                 // layer-1 output tile
@@ -51,6 +63,7 @@ constexpr int ST_OUT2_BYTES = ST_TH * ST_TW * ST_O2PITCH;    // 10240
 constexpr int ST_W2PITCH = 64 * 2 + 16;                      // tail filter row pitch: 128 B rows would put all 16 lanes of a
                                                              // fragment read on two banks (8-way conflict)
 constexpr int ST_W2_BYTES = 32 * ST_W2PITCH;                 // tail filters [32][64] bf16, kept in LDS (no registers left)
+constexpr int ST_B1_BYTES = 64 * 4;                          // layer-1 bias: read from LDS in the epilogue (16 VGPRs the filters need)
 constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
                                                              // would make hipcc wait vmcnt(0) and drain the input prefetch
 
@@ -73,11 +86,14 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             fw1[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w1 + (size_t)(ct * 16 + l15) * a.Kpad1 + t * 32 + lq * 8);
-    float4 b0v[2], b1v[4];
+    f32x4 b0v[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) b0v[i] = *(const float4 *)(a.b0 + i * 16 + lq * 4);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) b1v[ct] = *(const float4 *)(a.b1 + ct * 16 + lq * 4);
+    for (int i = 0; i < 2; ++i) b0v[i] = *(const f32x4 *)(a.b0 + i * 16 + lq * 4);
+    const float slope0 = a.act0 == ACT_LEAKY ? 0.1f : 1.f, slope1 = a.act1 == ACT_LEAKY ? 0.1f : 1.f, slope2 = a.act2 == ACT_LEAKY ? 0.1f : 1.f;
+    // phase A: byte offsets of this lane's taps lq and 4 + lq relative to its pixel in the input tile, packed into one register (the
+    // filter fragments leave none to spare); tap 8 + lq exists for lq == 0 only (the others are K padding: they read the zero slot)
+    const int tap0 = lq, tap1 = 4 + lq;
+    const int tapoff01 = (((tap0 * 11) >> 5) * ST_IW + tap0 - 3 * ((tap0 * 11) >> 5)) * 16 | ((((tap1 * 11) >> 5) * ST_IW + tap1 - 3 * ((tap1 * 11) >> 5)) * 16) << 16;
 
     const int tiles_x = (a.Wo + ST_TW - 1) / ST_TW, tiles_y = (a.Ho + ST_TH - 1) / ST_TH;
     const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
@@ -127,28 +143,19 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 const int ly = (idx * 1986) >> 16;               // idx / 33 for idx < 576
                 const int lx = idx - ly * ST_LW;
                 const bool inside = idx < ST_NPIX && (unsigned)(gy0 + ly) < (unsigned)a.H && (unsigned)(gx0 + lx) < (unsigned)a.W;
+                // layer-0 pixel (ly, lx) sits at input-region pixel (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw).  (The
+                // rows past the tile, idx >= ST_NPIX, read defined bytes of the fetched pieces and are zeroed below.)
+                const int pbase = (ly * ST_IW + lx) * 16;
                 bf16x8 fx[3];
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const int tap = kk * 4 + lq;
-                    const int kh = (tap * 11) >> 5, kw = tap - kh * 3;
-                    // layer-0 pixel (ly, lx) sits at input-region pixel (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw)
-                    const int q = (ly + kh) * ST_IW + lx + kw;
-                    const int off = (tap < 9 && idx < ST_NPIX) ? q * 16 : ST_INCHUNKS * 1024;      // else the zero slot
-                    fx[kk] = *(const bf16x8 *)(in_cur + off);
-                }
+                fx[0] = *(const bf16x8 *)(in_cur + pbase + (tapoff01 & 0xffff));
+                fx[1] = *(const bf16x8 *)(in_cur + pbase + (tapoff01 >> 16));
+                fx[2] = *(const bf16x8 *)(in_cur + (lq == 0 ? pbase + (2 * ST_IW + 2) * 16 : ST_INCHUNKS * 1024));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[i][kk], fx[kk], acc, 0, 0, 0);
-                    float v[4] = {acc[0] + b0v[i].x, acc[1] + b0v[i].y, acc[2] + b0v[i].z, acc[3] + b0v[i].w};
-                    if (a.act0 == ACT_LEAKY)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);       // == v > 0 ? v : 0.1 v, two VALU ops
-                    uint2 pk;
-                    pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
-                    pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
+                    uint2 pk = stem_epi(acc, b0v[i], slope0);
                     if (!inside) pk = uint2{0, 0};               // layer 1's zero padding, and the unused tail rows
                     *(uint2 *)(l0 + idx * ST_PITCH + (i * 16 + lq * 4) * 2) = pk;
                 }
@@ -172,14 +179,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         // ---- epilogue: bias + activation -> bf16 -> LDS -> 16-B stores ----
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            float v[4] = {acc1[ct][0] + b1v[ct].x, acc1[ct][1] + b1v[ct].y, acc1[ct][2] + b1v[ct].z, acc1[ct][3] + b1v[ct].w};
-            if (a.act1 == ACT_LEAKY)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);       // == v > 0 ? v : 0.1 v, two VALU ops
-            uint2 pk;
-            pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
-            pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
-            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = pk;
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi(acc1[ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
         }
         // staged tile complete, every wave done with the layer-0 tile, and the next tile's input has landed
         __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
@@ -207,15 +207,8 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float4 bv = *(const float4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4);
-                float v[4] = {acc2[i][0] + bv.x, acc2[i][1] + bv.y, acc2[i][2] + bv.z, acc2[i][3] + bv.w};
-                if (a.act2 == ACT_LEAKY)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
-                uint2 pk;
-                pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
-                pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
-                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = pk;
+                const f32x4 bv = *(const f32x4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4);
+                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi(acc2[i], bv, slope2);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
@@ -238,6 +231,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             *(uint4 *)(lw2 + row * ST_W2PITCH + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
             if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
         }
+    if (tid < 64) *(float *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + tid * 4) = a.b1[tid];
     if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile, inb0);
@@ -277,9 +271,10 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             fw[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w + (size_t)(ct * 16 + l15) * a.Kpad + t * 32 + lq * 8);
-    float4 bv[4];
+    f32x4 bv[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const float4 *)(a.b + ct * 16 + lq * 4);
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const f32x4 *)(a.b + ct * 16 + lq * 4);
+    const float slope = a.act == ACT_LEAKY ? 0.1f : 1.f;
 
     const int tiles_x = (a.W + ST_TW - 1) / ST_TW, tiles_y = (a.H + ST_TH - 1) / ST_TH;
     const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
@@ -340,14 +335,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            float v[4] = {acc[ct][0] + bv[ct].x, acc[ct][1] + bv[ct].y, acc[ct][2] + bv[ct].z, acc[ct][3] + bv[ct].w};
-            if (a.act == ACT_LEAKY)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
-            uint2 pk;
-            pk.x = stem_bf16(v[0]) | (stem_bf16(v[1]) << 16);
-            pk.y = stem_bf16(v[2]) | (stem_bf16(v[3]) << 16);
-            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = pk;
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi(acc[ct], bv[ct], slope);
         }
         // staged tile complete, every wave done with this tile's input, next input and this tile's shortcut have landed
         __builtin_amdgcn_s_waitcnt(0x0070);
@@ -365,7 +353,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
                 for (int q = 0; q < 4; ++q) {
                     const float lo_ = __builtin_bit_cast(float, ov[q] << 16) + __builtin_bit_cast(float, rv[q] << 16);
                     const float hi_ = __builtin_bit_cast(float, ov[q] & 0xffff0000u) + __builtin_bit_cast(float, rv[q] & 0xffff0000u);
-                    ov[q] = stem_bf16(lo_) | (stem_bf16(hi_) << 16);
+                    ov[q] = stem_pk(lo_, hi_);
                 }
                 o = uint4{ov[0], ov[1], ov[2], ov[3]};
             }
@@ -421,7 +409,7 @@ bool conv_stem_ok(const StemArgs &a)
 hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES;
+    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES + ST_B1_BYTES;
     { hipError_t e = conv_opt_in_lds((const void *)conv_stem_c32_c64, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
