@@ -442,3 +442,34 @@ def test_stem_and_halo_kernels_at_full_size_vs_oracle(hiplib):
     det = prod.forward(img)
     prod.close()
     assert np.array_equal(det, det_layers)
+
+
+def test_fused_1x1_tail_halo_forms_full_size(hiplib):
+    """The same at 416 x 416, where the free-running halo forms apply: 256-channel producers under f176c256 (cfg 40), 128-channel
+    producers (the 104 x 104 stage) under f176c128 (cfg 41, four tail channel tiles over eight waves), against the plan that
+    materialises every layer."""
+    txt = IO.cfg_text("yolov3")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=6)
+    img = np.random.default_rng(10).integers(0, 256, (1, 416, 416, 3), dtype=np.uint8)
+    ref = hiplib.Engine(txt, max_batch=1, dtype=hiplib.BF16, keep_layers=True)
+    ref.set_weights(flat); want = ref.forward(img); ref.close()
+    eng = hiplib.Engine(txt, max_batch=1, dtype=hiplib.BF16)
+    eng.set_weights(flat)
+    cfgs = np.full(eng.num_layers, -1, np.int32)
+    fused = {128: 0, 256: 0}
+    for i, s in enumerate(secs[1:]):
+        if s["type"] != "convolutional" or int(s["filters"]) not in (128, 256):
+            continue
+        for cand in ((41,) if int(s["filters"]) == 128 else (40, 32)):
+            trial = cfgs.copy(); trial[i] = cand + 10000
+            try:
+                eng.set_tile_configs(trial)
+                cfgs = trial; fused[int(s["filters"])] += 1
+                break
+            except hiplib.YoloError:
+                pass
+    assert fused[256] >= 10 and fused[128] >= 1, fused
+    eng.set_tile_configs(cfgs)
+    assert np.array_equal(eng.forward(img), want)
+    eng.close()
+

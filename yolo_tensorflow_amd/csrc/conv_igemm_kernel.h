@@ -330,7 +330,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // consumer waves split the C2 = BC / 2 tail channels 16 apiece
     // (8-wave shapes only: in the 4-wave 176x128 shapes the extra live registers push the kernel past 256 VGPRs and cost the
     // second resident workgroup per CU -- measured slower overall even where the pair itself got faster)
-    constexpr bool TAIL_OK = !DIAG && WP == 1 && NC == 8 && NC * 16 == BC / 2;
+    // (bf16: not in the role-split shapes -- the tail's addresses, hoisted above the K loop, push their 168-VGPR budget into spills)
+    constexpr bool TAIL_OK = WP == 1 && NC == 8 && (EB == 2 ? NL == 0 && (BC == 256 || BC == 128) : BC == 256);
     // (Tried and dropped: placing one LDS-DMA of the next stage behind every MFMA group with sched_group_barrier instead of
     // issuing the whole stage first.  A/B on one MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms)
     // and fp8 (2.39 vs 2.34 ms) -- a DMA blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     }
     int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
     // DIAG (separate diagnostic instantiation, never the shipped kernel): s_memtime stamps around the phases of a K-step
-    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0, t_first = 0, te1 = 0, te2 = 0, te3 = 0;
+    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0, t_first = 0, te1 = 0, te2 = 0, te3 = 0, te4 = 0, te5 = 0, te6 = 0;
     auto stamp = [&]() -> unsigned long long {
         unsigned long long t = 0;
         if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
@@ -659,14 +660,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 }
             }
         }
-        // fused 1x1 tail: its filter fragments (16 rows x BC per consumer wave) are fetched here when the registers allow
-        // (8-wave shapes), so their latency hides behind the epilogue; the 4-wave shapes fetch them just before use
-        constexpr bool TAIL_EARLY = TAIL_OK && NL == 0 && EB == 2;   // the 12-wave role-split shape has no registers to spare
-        bf16x8 fw2[TAIL_OK && EB == 2 ? BC / 32 : 1];
-        if (TAIL_EARLY) if (a.w2 && is_consumer)
-#pragma unroll
-            for (int kk = 0; kk < BC / 32; ++kk)
-                fw2[kk] = *(const bf16x8 *)((const bf16_t *)a.w2 + (size_t)(wave_id * 16 + l15) * a.K2pad + (kk * 4 + lq) * 8);
         // halo form: MFMA column (j, l15) holds pixel kHaloPerm13[..] >> 8 of the block; the LDS tile is in raster order
         int prow[HALO ? TP : 1];
         if constexpr (HALO) {
@@ -701,6 +694,22 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();
         if (DIAG) te2 = stamp();
+        // fused 1x1 tail (bf16): eight consumer waves = T2G groups of T2W 16-channel tiles x T2P parts of the tile's pixel sub-tiles
+        // (T2W = 2 in the halo forms, 1 in the tiled 8-wave shape, which has no registers for 64 of filter fragments).  A wave's filter
+        // fragments (16 T2W rows x BC) are fetched here -- the accumulators are dead, the store loop below covers the latency
+        constexpr int C2 = BC / 2, K2S = BC / 32, T2W = HALO ? 2 : 1, T2G = (C2 / (16 * T2W)) > 0 ? C2 / (16 * T2W) : 1, T2P = 8 / T2G > 0 ? 8 / T2G : 1;
+        const int t2g = wave_id % T2G, t2p = wave_id / T2G;
+        bf16x8 fw2[TAIL_OK && EB == 2 ? T2W : 1][TAIL_OK && EB == 2 ? K2S : 1];
+        auto load_fw2 = [&]() {
+            if constexpr (TAIL_OK && EB == 2)
+                if (a.w2 && is_consumer)
+#pragma unroll
+                    for (int t = 0; t < T2W; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < K2S; ++kk)
+                            fw2[t][kk] = *(const bf16x8 *)((const bf16_t *)a.w2f + ((size_t)((t2g * T2W + t) * K2S + kk) * 64 + lane) * 8);
+        };
+        load_fw2();
         if (out8) {
             // e4m3 output: the bf16-rounded value times 1/scale, RNE, saturating (shortcut: see below)
 #pragma unroll
@@ -790,79 +799,102 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 }
             }
         } else {
+            // The loop is written out with and without the shortcut: with that run-time condition inside it, the compiler's s_waitcnt
+            // vmcnt for a shortcut piece is the minimum over the merged paths (vmcnt(5)), which also waits for the stores of the previous
+            // pieces to COMPLETE -- five memory operations in flight per wave instead of all of them.  (The tail's write-back stays a
+            // run-time branch: an LDS store does not touch vmcnt, and a third copy of the loop costs registers.)
+            const bool tail_wb = TAIL_OK && EB == 2 && a.w2;
+            auto store_tile = [&](auto resc) {
+                constexpr bool RES = decltype(resc)::value;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                int row, cc;
-                const unsigned off = piece_off(tid + it * NT, CPR, 8, out_sb, row, cc);
-                if ((BP * CPR) % NT != 0 && tid + it * NT >= BP * CPR) continue;       // (only shapes whose piece count is ragged)
-                u32x4_t o = *(const u32x4_t *)(smem + row * RS + cc * 16);
-                if (res) {
-                    // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
-                    // by a separate shortcut kernel; the sum is rounded once more
-                    const u32x4_t r = rpre[it];
+                for (int it = 0; it < NIT; ++it) {
+                    int row, cc;
+                    const unsigned off = piece_off(tid + it * NT, CPR, 8, out_sb, row, cc);
+                    if ((BP * CPR) % NT != 0 && tid + it * NT >= BP * CPR) continue;       // (only shapes whose piece count is ragged)
+                    u32x4_t o = *(const u32x4_t *)(smem + row * RS + cc * 16);
+                    if constexpr (RES) {
+                        // the layer's own output was rounded to bf16 above, exactly as if it had been stored and re-read
+                        // by a separate shortcut kernel; the sum is rounded once more
+                        const u32x4_t r = rpre[it];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float lo = __builtin_bit_cast(float, o[q] << 16) + __builtin_bit_cast(float, r[q] << 16);
-                        const float hi = __builtin_bit_cast(float, o[q] & 0xffff0000u) + __builtin_bit_cast(float, r[q] & 0xffff0000u);
-                        o[q] = f32x2_to_bf16x2(lo, hi);
+                        for (int q = 0; q < 4; ++q) {
+                            const float lo = __builtin_bit_cast(float, o[q] << 16) + __builtin_bit_cast(float, r[q] << 16);
+                            const float hi = __builtin_bit_cast(float, o[q] & 0xffff0000u) + __builtin_bit_cast(float, r[q] & 0xffff0000u);
+                            o[q] = f32x2_to_bf16x2(lo, hi);
+                        }
+                        if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
-                    if (TAIL_OK && EB == 2 && a.w2) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
-            }
+            };
+            if (res) store_tile(std::true_type{}); else store_tile(std::false_type{});
             if (DIAG) te3 = stamp();
             if constexpr (TAIL_OK && EB == 2) if (a.w2) {
-                // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.
-                //      Consumer wave w owns output channels 16w..16w+15 for every pixel of the tile; its filter fragments
-                //      (16 rows x BC, 8 KB) come straight from global; K is walked in ascending 32-wide steps, the order of
-                //      the stand-alone 1x1 kernel, so the result is bit-identical to the unfused layer. ----
-                constexpr int C2 = BC / 2, K2S = BC / 32, RS2 = C2 * 2 + 16;
+                // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.  Wave (t2g, t2p)
+                //      owns output channels 32 t2g .. 32 t2g + 31 for the pixel sub-tiles of part t2p: every pixel fragment it reads
+                //      feeds two MFMAs (the tail is LDS-read-bound: one fragment per MFMA in the one-channel-tile-per-wave form cost
+                //      twice the LDS traffic).  K is walked in ascending 32-wide steps, the order of the stand-alone 1x1 kernel, so
+                //      the result is bit-identical to the unfused layer. ----
+                constexpr int RS2 = C2 * 2 + 16;
                 char *const st2 = smem + BP * RS;
-                if (!TAIL_EARLY && is_consumer)
-#pragma unroll
-                    for (int kk = 0; kk < K2S; ++kk)
-                        fw2[kk] = *(const bf16x8 *)((const bf16_t *)a.w2 + (size_t)(wave_id * 16 + l15) * a.K2pad + (kk * 4 + lq) * 8);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 block_barrier();                                   // tile (with the shortcut added) complete in LDS
+                if (DIAG) te4 = stamp();
                 if (is_consumer) {
-                    const float4 b2v = *(const float4 *)(a.b2 + wave_id * 16 + lq * 4);
-                    auto finish = [&](const f32x4 &acc2, int j) {
-                        float v[4] = {acc2[0] + b2v.x, acc2[1] + b2v.y, acc2[2] + b2v.z, acc2[3] + b2v.w};
-                        if (a.act2 == ACT_LEAKY) {
+                    const float slope2 = a.act2 == ACT_LEAKY ? 0.1f : 1.0f;
+                    f32x4 b2v[T2W];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);
-                        }
-                        uint2 pk;
-                        pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
-                        pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
-                        *(uint2 *)(st2 + (j * 16 + l15) * RS2 + (wave_id * 16 + lq * 4) * 2) = pk;
+                    for (int t = 0; t < T2W; ++t) b2v[t] = *(const f32x4 *)(a.b2 + (t2g * T2W + t) * 16 + lq * 4);
+                    auto finish = [&](const f32x4 &acc2, int j, int t) {
+                        f32x4 v = acc2 + b2v[t];
+                        const f32x4 u = v * slope2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], u[q]);
+                        *(uint2 *)(st2 + (j * 16 + l15) * RS2 + ((t2g * T2W + t) * 16 + lq * 4) * 2) = uint2{f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3])};
                     };
-                    // two pixel tiles at a time: two independent accumulation chains keep the matrix pipe fed (each chain
-                    // is K-ordered); the loop stays rolled so the fragment reads are not all hoisted (176 VGPRs otherwise)
+                    const int j0 = (TP * t2p) / T2P, j1 = (TP * (t2p + 1)) / T2P;       // this wave's pixel sub-tiles
+                    // Two sub-tiles at a time: 2 T2W independent accumulation chains, each K-ordered; the loop stays rolled so the fragment
+                    // reads are not all hoisted.  (Reading the next pair's fragments under the MFMAs of the current one -- a second
+                    // 64-register buffer -- measured slower in the stamped build, 5500 vs 4650 cycles.)
+                    {
+                        int j = j0;
 #pragma unroll 1
-                    for (int j = 0; j + 1 < TP; j += 2) {
-                        f32x4 acc2a = {0.f, 0.f, 0.f, 0.f}, acc2b = {0.f, 0.f, 0.f, 0.f};
+                        for (; j + 1 < j1; j += 2) {
+                            f32x4 ca[T2W], cb[T2W];
 #pragma unroll
-                        for (int kk = 0; kk < K2S; ++kk) {
-                            const bf16x8 xa = *(const bf16x8 *)(smem + (j * 16 + l15) * RS + (kk * 4 + lq) * 16);
-                            const bf16x8 xb = *(const bf16x8 *)(smem + ((j + 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
-                            acc2a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], xa, acc2a, 0, 0, 0);
-                            acc2b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], xb, acc2b, 0, 0, 0);
-                        }
-                        finish(acc2a, j); finish(acc2b, j + 1);
-                    }
-                    if (TP & 1) {
-                        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                            for (int t = 0; t < T2W; ++t) ca[t] = cb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kk = 0; kk < K2S; ++kk) {
-                            const bf16x8 x = *(const bf16x8 *)(smem + ((TP - 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
-                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[kk], x, acc2, 0, 0, 0);
+                            for (int kk = 0; kk < K2S; ++kk) {
+                                const bf16x8 xa = *(const bf16x8 *)(smem + (j * 16 + l15) * RS + (kk * 4 + lq) * 16);
+                                const bf16x8 xb = *(const bf16x8 *)(smem + ((j + 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
+#pragma unroll
+                                for (int t = 0; t < T2W; ++t) {
+                                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], xa, ca[t], 0, 0, 0);
+                                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], xb, cb[t], 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int t = 0; t < T2W; ++t) { finish(ca[t], j, t); finish(cb[t], j + 1, t); }
                         }
-                        finish(acc2, TP - 1);
+                        if (j < j1) {
+                            f32x4 cc_[T2W];
+#pragma unroll
+                            for (int t = 0; t < T2W; ++t) cc_[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kk = 0; kk < K2S; ++kk) {
+                                const bf16x8 x = *(const bf16x8 *)(smem + (j * 16 + l15) * RS + (kk * 4 + lq) * 16);
+#pragma unroll
+                                for (int t = 0; t < T2W; ++t) cc_[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], x, cc_[t], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int t = 0; t < T2W; ++t) finish(cc_[t], j, t);
+                        }
                     }
                 }
+                if (DIAG) te5 = stamp();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 block_barrier();
+                if (DIAG) te6 = stamp();
                 constexpr int CPR2 = C2 / 8;
                 const __amdgpu_buffer_rsrc_t rs_out2 = tile_rsrc((char *)a.out2 + m0 * a.out2_stride * 2);
 #pragma unroll
@@ -903,10 +935,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (DIAG && a.dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = stamp();
-        unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 12;
+        unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 16;
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end;
-        d[6] = t_all0 - t_top; d[7] = t_first - t_all0; d[8] = te1 - t_loop_end; d[9] = te2 - te1; d[10] = te3 - te2; d[11] = t_end - te3;
+        d[6] = t_all0 - t_top; d[7] = t_first - t_all0; d[8] = te1 - t_loop_end; d[9] = te2 - te1; d[10] = te3 - te2; d[11] = t_end - (te6 ? te6 : te3);
+        d[12] = te4 ? te4 - te3 : 0; d[13] = te4 ? te5 - te4 : 0; d[14] = te4 ? te6 - te5 : 0; d[15] = 0;
         d[5] = ((unsigned long long)KT << 40) | ((t_end - t_all0) * 100ull / (rt1 - rt0 ? rt1 - rt0 : 1));   // KT | shader MHz (realtime = 100 MHz)
     }
 #endif
@@ -920,7 +953,7 @@ constexpr size_t conv_lds_bytes()
     constexpr int RG = 64 / (BK * 2 / 16);
     constexpr int LA = ((BP + RG - 1) / RG + NW - 1) / NW, LB = ((BC + RG - 1) / RG + NW - 1) / NW;
     constexpr size_t stage = (size_t)(LA + LB) * NW * RG * (BK * 2);
-    constexpr bool tail = WP == 1 && WC == 8 && WC * 16 == BC / 2; // TAIL_OK shapes also stage the tail's [BP][BC/2] tile
+    constexpr bool tail = WP == 1 && WC == 8 && (BC == 256 || BC == 128); // TAIL_OK shapes also stage the tail's [BP][BC/2] tile
     constexpr size_t lds0 = HALO ? (size_t)2 * HALO_ACT_BYTES + (size_t)NS * LB * NW * RG * (BK * 2) : (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16) + (tail ? (size_t)BP * (BC + 16) : 0);
     return lds0 > ldso ? lds0 : ldso;
 }

@@ -38,6 +38,7 @@ struct ConvArgs {
     // computed from the finished output tile while it is still in LDS (the 1x1 conv that follows a 3x3 in every darknet
     // residual block).  w2 == nullptr: none.  C2 = Cout / 2, W2 packed [C2 pad][K2pad], k = channel of `out`.
     const void *w2; const float *b2; void *out2; int out2_stride, K2pad, act2;
+    const void *w2f;                     // bf16 tail: W2 in MFMA-fragment order [C2 / 16][K2 / 32][64 lanes][8] (yolo_api.cpp tail_fragments)
     const float *oscale2; float out2_inv_scale;      // fp8 tail: per-channel dequantisation scale of W2, 1 / scale of out2
     int N, H, W, Cin_pad;
     int Ho, Wo, Cout;
@@ -94,7 +95,7 @@ bool conv_halo13_ok(const ConvArgs &a);
 bool conv_cfg_is_halo(int cfg);
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant = 0);   // 0: eight waves of 176 x 32 (the shipped shape), 1: four waves of 176 x 64      // stamped free-running 176x256 build (tools only)
-bool conv_cfg_tail_ok(int cfg, int cout);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
+bool conv_cfg_tail_ok(int cfg, int cout, bool fp8);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);

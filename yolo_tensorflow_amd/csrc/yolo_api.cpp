@@ -36,6 +36,7 @@ struct Layer {
     int filters = 0, size = 0, stride = 1, pad = 0, bn = 0, act = ACT_LINEAR;
     int cin = 0, cin_pad = 0, kpad = 0, cout_pad = 0;
     void *d_w = nullptr; float *d_b = nullptr; float *d_sc = nullptr;   // filters, bias, fp8 per-channel dequant scale
+    void *d_wf = nullptr;                   // bf16 1x1 conv that can ride in its producer's epilogue: its filters in MFMA-fragment order (tail_fragments)
     int in_dt = DT_BF16;                 // operand type of this conv's MFMA (filters are stored in it)
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
@@ -493,7 +494,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
     if (L.tail_on && L.tail_layer >= 0) {
         const Layer &T = c->layers[L.tail_layer];
-        a.w2 = T.d_w; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
+        a.w2 = T.d_w; a.w2f = T.d_wf; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
         a.oscale2 = T.d_sc; a.out2_inv_scale = T.out.dt == DT_FP8 ? 1.f / c->eff_scale[L.tail_layer] : 1.f;
     }
     if (L.out.dt == DT_FP8) {
@@ -546,13 +547,13 @@ int run_layer(yolo_ctx *c, int i, int n)
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
             if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
-            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_fp8(a, cfg, s));
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
             if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);
-            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
         break; }
@@ -774,7 +775,7 @@ void yolo_destroy(yolo_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void *p : c->phys) if (p) hipFree(p);
-    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); }
+    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); if (L.d_wf) hipFree(L.d_wf); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
                     c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -797,6 +798,32 @@ int yolo_set_act_scales(yolo_ctx *c, const float *scales, int n)
     resolve_scales(c);
     c->weights_loaded = false;           // filters absorb the input scales: they have to be packed again
     if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0;
+    return YOLO_OK;
+}
+
+// The fused 1x1 tail (conv_igemm_kernel.h) reads its filters as MFMA A fragments straight from global memory: lane (l15, lq) of a wave
+// takes the 16 bytes at k = (kk * 4 + lq) * 8 of row ct2 * 16 + l15.  From the [row][K] image one such wave-load touches sixteen
+// 64-byte pieces 2 * K bytes apart, and every workgroup of the layer asks for the same 64 KB at the same moment; a copy in fragment
+// order -- [channel tile][K step][lane][8 bf16] -- makes each wave-load one contiguous KiB.  Built from the packed filters already on
+// the device, so both ways of loading parameters (weight stream, export artifact) share it.
+static int tail_fragments(yolo_ctx *c)
+{
+    if (c->dtype != YOLO_BF16) return YOLO_OK;
+    std::vector<uint16_t> src, dst;
+    for (auto &T : c->layers) {
+        if (T.type != L_CONV || T.fused_into < 0) continue;
+        const int C2 = T.filters, K = T.kpad;                        // K == the producer's channel count, a multiple of 32
+        if (C2 % 16 || K % 32) continue;
+        src.resize((size_t)T.cout_pad * K); dst.resize((size_t)C2 * K);
+        HIPCK(c, hipMemcpy(src.data(), T.d_w, src.size() * 2, hipMemcpyDeviceToHost));
+        const int K2S = K / 32;
+        for (int ct2 = 0; ct2 < C2 / 16; ++ct2)
+            for (int kk = 0; kk < K2S; ++kk)
+                for (int lane = 0; lane < 64; ++lane)
+                    memcpy(&dst[(((size_t)ct2 * K2S + kk) * 64 + lane) * 8], &src[(size_t)(ct2 * 16 + (lane & 15)) * K + (kk * 4 + (lane >> 4)) * 8], 16);
+        if (!T.d_wf) HIPCK(c, hipMalloc(&T.d_wf, dst.size() * 2));
+        HIPCK(c, hipMemcpy(T.d_wf, dst.data(), dst.size() * 2, hipMemcpyHostToDevice));
+    }
     return YOLO_OK;
 }
 
@@ -845,6 +872,7 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));
     }
+    if (int rc = tail_fragments(c)) return rc;
     c->weights_loaded = true;
     return YOLO_OK;
 }
@@ -955,6 +983,7 @@ yolo_ctx *yolo_create_from_file(const char *path, int max_batch, int device, voi
     }
     uint64_t sum = 0; const bool got = fread(&sum, 1, 8, f) == 8; fclose(f);
     if (!got || sum != r.h) return bail(c, "artifact checksum mismatch");
+    if (tail_fragments(c) != YOLO_OK) return bail(c, c->err);
     c->weights_loaded = true;
     // the tile plan is only meaningful for the tile table it was tuned with and for a plan that fuses nothing it cannot
     if (hd.num_cfgs == (uint32_t)conv_num_cfgs() && !keep_layers) { if (yolo_set_tile_configs(c, plan.data()) != YOLO_OK) { std::vector<int32_t> none(hd.n_layers, -1); yolo_set_tile_configs(c, none.data()); } }
@@ -1342,7 +1371,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int i = 0; i < NL; ++i) {
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
-                bool ok = conv_cfg_tail_ok(cfg, L.filters);
+                bool ok = conv_cfg_tail_ok(cfg, L.filters, c->dtype == YOLO_FP8);
                 if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo13_ok(a); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
@@ -1389,7 +1418,7 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
         int v = cfgs[i]; bool tail = false;
         if (v >= 10000) { v -= 10000; tail = true; }
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
-        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters)))
+        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->dtype == YOLO_FP8)))
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
         if (tail && conv_cfg_is_halo(v)) {
             ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
@@ -1452,19 +1481,25 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         const bool dfree = (dwide || !strcmp(getenv("YOLO_CONV_DIAG"), "free")) && conv_halo13_ok(a) && dt == DT_BF16;
         const int wv = dfree && !dwide ? 8 : 4;
         const long tiles = dfree ? (long)n * (h / 13) * (w / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
-        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 12 * 8);
+        a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 16 * 8);
+        if (dfree && !dwide && getenv("YOLO_CONV_DIAG_TAIL") && cout == 256) {
+            // time the fused 1x1 tail too: any 128 x 256 filter block will do (the main filters' first rows), output to scratch
+            a.w2 = a.wt; a.w2f = a.wt; a.K2pad = a.Kpad; a.b2 = a.bias; a.act2 = ACT_LEAKY; a.out2_stride = 128;
+            a.out2 = S.alloc((size_t)n * ho * wo * 128 * 2);
+        }
         for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s, dwide ? 1 : 0) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
-        std::vector<unsigned long long> hd((size_t)tiles * wv * 12);
+        std::vector<unsigned long long> hd((size_t)tiles * wv * 16);
         S.download(hd.data(), a.dbg, hd.size() * 8);
-        double sum[12] = {0}; size_t cnt = hd.size() / 12;
+        double sum[16] = {0}; size_t cnt = hd.size() / 16;
         const unsigned long long kt = hd[5] >> 40;
         for (size_t i = 0; i < cnt; ++i)
-            for (int q = 0; q < 12; ++q) sum[q] += q == 5 ? (double)(hd[i * 12 + 5] & 0xffffffffffull) : (double)hd[i * 12 + q];
+            for (int q = 0; q < 16; ++q) sum[q] += q == 5 ? (double)(hd[i * 16 + 5] & 0xffffffffffull) : (double)hd[i * 16 + q];
         for (double &v : sum) v /= cnt;
         fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz\n",
                 cnt, kt, sum[0] / kt, sum[1] / kt, sum[2] / kt, sum[3] / kt, sum[4], sum[5]);
         fprintf(stderr, "diag: setup (first instruction -> prologue issued) %.0f | first wait (prologue data + barrier) %.0f | epilogue: barrier %.0f  acc->LDS + barrier %.0f  shortcut add + store issue %.0f  store drain %.0f\n",
                 sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
+        if (a.w2) fprintf(stderr, "diag: fused 1x1 tail: barrier %.0f  fragments + MFMA + pack %.0f  barrier %.0f (then the tail's stores, in `store drain`)\n", sum[12], sum[13], sum[14]);
     } else
         e = f32 ? launch_conv_f32(a, S.s)
                 : dt == DT_FP8 ? launch_conv_fp8(a, tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(a), S.s)
