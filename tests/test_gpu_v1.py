@@ -113,3 +113,37 @@ def test_v1_errors_are_codes(hiplib):
         hiplib.Engine(bad, max_batch=1)
     with pytest.raises(hiplib.YoloError, match="unsupported|fp8"):       # the fp8 configuration serves neither the 7x7 conv nor [connected]
         hiplib.Engine(IO.cfg_text("yolov1"), max_batch=1, dtype=hiplib.FP8)
+
+
+def test_yolov1_tiny_network_and_entry_point(hiplib, tmp_path):
+    """The tiny YOLOv1 of D2T/YOLO_V1_Tiny_convert_darkenet_to_Tensorflow.py (eight BN convs, six max-pools, one FC; input x / 255,
+    RGB): the 1470 predictions vs the fp32 oracle, and `YOLOV1_Tiny(weights_file).detect_from_file` vs the oracle's detector with
+    that script's thresholds (0.1 / 0.6 / 10)."""
+    from PIL import Image
+    from yolo_tensorflow_amd.yolo_v1 import YOLOV1_Tiny
+    txt = IO.cfg_text("yolov1-tiny")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=8)
+    assert flat.size == IO.weights_count(secs)
+    img = np.random.default_rng(22).integers(0, 256, (448, 448, 3), dtype=np.uint8)
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    heads, _ = R.forward(osecs, params, (img.astype(np.float32) / np.float32(255))[None])
+    pred = heads[0][1].reshape(-1)
+    want = R.v1_rows(pred, 7, 2, 20)
+    for dtype, tol in ((hiplib.FP32, 2e-3), (hiplib.BF16, 5e-2)):
+        eng = hiplib.Engine(txt, max_batch=2, dtype=dtype)
+        eng.set_weights(flat)
+        det = eng.forward(np.stack([img, img[::-1].copy()]))
+        assert det.shape == (2, 98, 25) and np.isfinite(det).all()
+        assert _relmax(det[0], want) < tol, "dtype %d: %g" % (dtype, _relmax(det[0], want))
+        eng.close()
+    wf = str(tmp_path / "tiny-yolov1.weights"); IO.write_weights_file(wf, flat, 0, 1)
+    png = str(tmp_path / "img.png"); Image.fromarray(img).save(png)
+    y = YOLOV1_Tiny(wf, verbose=False, dtype=hiplib.FP32)
+    out = y.detect_from_file(png, imshow=False, deteted_boxes_file=str(tmp_path / "boxes.txt"))
+    y.close()
+    wb, ws, wc = R.detect_v1_tf(pred, 7, 2, 20, 0.1, 0.6, 10)
+    assert len(out) == len(ws) > 0
+    for (name, bx, by, bw, bh, s), b, sc, c in zip(out, wb, ws, wc):
+        assert name == IO.v1_classes()[int(c)] and abs(s - sc) < 2e-3
+        np.testing.assert_allclose([bx, by, bw, bh], b * np.float32(448), rtol=2e-3, atol=0.5)
+

@@ -194,10 +194,23 @@ def yolov1(size=448, classes=20):
     return c.text()
 
 
+def yolov1_tiny(size=448, classes=20):
+    """D2T/YOLO_V1_Tiny_convert_darkenet_to_Tensorflow.py:256-322 `_build_network`: eight BN + leaky 3x3 convs (16 .. 1024, 256), a
+    2x2 max-pool after each of the first six, the CHW flatten and one fully connected layer of S*S*(C + 5 B) = 1470 linear outputs;
+    input x / 255 (`_input_process`, :212-216)."""
+    c = Cfg(size)
+    for f in (16, 32, 64, 128, 256, 512):
+        c.conv(f, 3); c.maxpool()
+    c.conv(1024, 3); c.conv(256, 3)
+    c.connected(7 * 7 * (classes + 2 * 5), act="linear")
+    c.detection(classes, 7, 2)
+    return c.text()
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     files = {
-        "yolov1.cfg": yolov1(448),
+        "yolov1.cfg": yolov1(448), "yolov1-tiny.cfg": yolov1_tiny(448),
         "yolov3.cfg": yolov3(416), "yolov3-608.cfg": yolov3(608),
         "yolov3-tiny.cfg": yolov3_tiny(416),
         "yolov2.cfg": yolov2(416), "yolov2-tiny-voc.cfg": yolov2_tiny_voc(416),

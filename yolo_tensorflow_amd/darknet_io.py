@@ -17,7 +17,7 @@ CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg")
 
 
 def cfg_text(name):
-    """Text of a shipped topology ('yolov3', 'yolov3-608', 'yolov3-tiny', 'yolov2', 'yolov2-tiny-voc', 'yolov1')
+    """Text of a shipped topology ('yolov3', 'yolov3-608', 'yolov3-tiny', 'yolov2', 'yolov2-tiny-voc', 'yolov1', 'yolov1-tiny')
     or of a cfg file path."""
     path = name if os.path.exists(name) else os.path.join(CFG_DIR, name + ".cfg")
     with open(path) as f:

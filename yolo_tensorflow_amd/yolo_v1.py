@@ -13,16 +13,20 @@ from . import hip, darknet_io as IO
 
 
 class Yolo(object):
+    CFG = "yolov1"
+    THRESHOLD, IOU_THRESHOLD, MAX_OUTPUT_SIZE = 0.2, 0.4, 10       # V1/YOLO_V1_Inference.py:47-49
+    BGR = True                                                       # the image reaches the network in cv2.imread's channel order
+
     def __init__(self, weights_file, input_image=None, verbose=True, dtype=hip.BF16, device=0, weights=None):
         self.verbose = verbose
         self.S = 7          # cells per side
         self.B = 2          # boxes per cell
         self.classes = IO.v1_classes()
         self.C = len(self.classes)
-        self.threshold = 0.2           # class-specific confidence threshold (`>=`)
-        self.iou_threshold = 0.4
-        self.max_output_size = 10
-        self.cfg_text = IO.cfg_text("yolov1")
+        self.threshold = self.THRESHOLD           # class-specific confidence threshold (`>=`)
+        self.iou_threshold = self.IOU_THRESHOLD
+        self.max_output_size = self.MAX_OUTPUT_SIZE
+        self.cfg_text = IO.cfg_text(self.CFG)
         self.engine = hip.Engine(self.cfg_text, max_batch=1, dtype=dtype, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO, device=device)
         self._load_weights(weights_file, weights)
         if input_image is not None:
@@ -70,7 +74,7 @@ class Yolo(object):
     def detect_from_file(self, image_file, imshow=True, deteted_boxes_file="boxes.txt", detected_image_file="detected_image.jpg"):
         from PIL import Image
         rgb = np.asarray(Image.open(image_file).convert("RGB"))
-        image = np.ascontiguousarray(rgb[:, :, ::-1])                  # cv2.imread: BGR
+        image = np.ascontiguousarray(rgb[:, :, ::-1]) if self.BGR else np.ascontiguousarray(rgb)      # cv2.imread: BGR
         scores, boxes, box_classes = self._detect_from_image(image)
         predict_boxes = []
         for i in range(len(scores)):
@@ -89,3 +93,20 @@ class Yolo(object):
                 f.write(r[0] + "," + str(x) + "," + str(y) + "," + str(w) + "," + str(h) + "," + str(r[5]) + "\n")
         if f:
             f.close()
+
+
+class YOLOV1_Tiny(Yolo):
+    """D2T/YOLO_V1_Tiny_convert_darkenet_to_Tensorflow.py:53-98 `YOLOV1_Tiny(weights_file, verbose=True)`: the eight-conv tiny YOLOv1
+    (`cfg/yolov1-tiny.cfg`), input x / 255 in RGB order (:212-216, :473-474), thresholds from that script's flags (:30-32), the same
+    `_build_detector` (:326-386) and `detect_from_image` / `detect_from_file` (:470-500).  `weights_file` is darknet's
+    tiny-yolov1.weights stream (4-int header, `_load_weights` :99-203)."""
+    CFG = "yolov1-tiny"
+    THRESHOLD, IOU_THRESHOLD, MAX_OUTPUT_SIZE = 0.1, 0.6, 10
+    BGR = False
+
+    def __init__(self, weights_file, verbose=True, dtype=hip.BF16, device=0, weights=None):
+        Yolo.__init__(self, weights_file, None, verbose, dtype, device, weights)
+
+    def detect_from_image(self, image):
+        return self._detect_from_image(image)
+
