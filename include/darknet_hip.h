@@ -11,8 +11,8 @@
  *   - load_image_color decodes binary PPM / PGM only (the reference uses the vendored stb_image for JPEG / PNG);
  *   - do_nms_* leave the array order unchanged (the reference qsorts it in place);
  *   - [region] heads are served in their softmax form (no tree / map / mask coefficients), hier_thresh and map are ignored;
- *   - network_predict* return net->output for networks whose last layer is a [yolo] / [region] head (every topology the
- *     reference's detectors use); precision is bf16 unless DARKNET_HIP_DTYPE=fp32 is set in the environment;
+ *   - network_predict* return net->output for networks whose last layer is a [yolo] / [region] / [detection] head (every
+ *     topology the reference's detectors use); precision is bf16 unless DARKNET_HIP_DTYPE=fp32 is set in the environment;
  *   - get_network_boxes reports the first image of a batch, as the reference does. */
 #ifndef DARKNET_HIP_H
 #define DARKNET_HIP_H

@@ -322,3 +322,53 @@ def test_python_detect_matches_reference_binding(pair, tmp_path):
                 hits += 1
                 break
     assert hits >= len(want) - 3
+
+
+def test_detection_head_matches_libdarknet(tmp_path, hiplib):
+    """A [detection] topology (YOLOv1 style: convs, max-pools, [connected], [dropout], [detection]; 4-int .weights header) through
+    both libraries: `network_predict_image` returns the prediction vector, `get_network_boxes` every one of the side*side*num boxes
+    in layer order with probabilities gated by the threshold (get_detection_detections, DN/detection_layer.c:225-254)."""
+    if not DR.available():
+        pytest.skip("oracle/_ref/libdarknet_ref.so not built")
+    os.environ["DARKNET_HIP_DTYPE"] = "fp32"
+    S, B, Cn = 4, 2, 5
+    txt = ("[net]\nbatch=1\nsubdivisions=1\nheight=64\nwidth=64\nchannels=3\n\n"
+           "[convolutional]\nbatch_normalize=1\nfilters=16\nsize=3\nstride=1\npad=1\nactivation=leaky\n\n[maxpool]\nsize=2\nstride=2\n\n"
+           "[convolutional]\nfilters=32\nsize=3\nstride=2\npad=1\nactivation=leaky\n\n[maxpool]\nsize=2\nstride=2\n\n"
+           "[convolutional]\nfilters=24\nsize=1\nstride=1\npad=1\nactivation=leaky\n\n[maxpool]\nsize=2\nstride=2\n\n"
+           "[connected]\noutput=96\nactivation=leaky\n\n[dropout]\nprobability=.5\n\n"
+           "[connected]\noutput=%d\nactivation=linear\n\n"
+           "[detection]\nclasses=%d\ncoords=4\nrescore=1\nside=%d\nnum=%d\nsoftmax=0\nsqrt=1\njitter=.2\n"
+           "object_scale=1\nnoobject_scale=.5\nclass_scale=1\ncoord_scale=5\n" % (S * S * (Cn + 5 * B), Cn, S, B))
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 31)
+    cfg = str(tmp_path / "v1.cfg"); wf = str(tmp_path / "v1.weights")
+    open(cfg, "w").write(txt); IO.write_weights_file(wf, flat, 0, 1)
+    ref = _bind(DR.lib())
+    ven = _bind(C.CDLL(os.path.join(ROOT, "yolo_tensorflow_amd", "libdarknet_hip.so")))
+    with DR._Quiet():
+        rnet = ref.load_network(cfg.encode(), wf.encode(), 0)
+        ref.set_batch_network(rnet, 1)
+    vnet = ven.load_network(cfg.encode(), wf.encode(), 0)
+    assert vnet
+    w, h = 90, 70
+    img = np.ascontiguousarray(np.random.default_rng(3).random((3, h, w), dtype=np.float32))
+    im = IMAGE(w, h, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+    n_out = S * S * (Cn + 5 * B)
+    outr = np.ctypeslib.as_array(ref.network_predict_image(rnet, im), shape=(n_out,)).copy()
+    pv = ven.network_predict_image(vnet, im); assert bool(pv)
+    outv = np.ctypeslib.as_array(pv, shape=(n_out,)).copy()
+    np.testing.assert_allclose(outv, outr, rtol=2e-4, atol=2e-5)
+    thresh = 0.25
+    nr, nv = C.c_int(0), C.c_int(0)
+    dr = ref.get_network_boxes(rnet, w, h, thresh, .5, None, 0, C.byref(nr))
+    dv = ven.get_network_boxes(vnet, w, h, thresh, .5, None, 0, C.byref(nv))
+    assert nv.value == nr.value == S * S * B
+    br, orr, pr = _collect(dr, nr.value, Cn); bv, ov, pvv = _collect(dv, nv.value, Cn)
+    np.testing.assert_allclose(bv, br, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(ov, orr, rtol=2e-4, atol=2e-5)
+    clear = np.abs(orr[:, None] * outr[:S * S * Cn].reshape(S * S, Cn).repeat(B, 0) - thresh) > 1e-3
+    assert np.array_equal((pvv > 0)[clear], (pr > 0)[clear]) and (pr > 0).any() and (pr == 0).any()
+    np.testing.assert_allclose(pvv[clear], pr[clear], rtol=2e-4, atol=2e-5)
+    ref.free_detections(dr, nr.value); ven.free_detections(dv, nv.value)
+    ven.free_network(vnet); ref.free_network(rnet)
+

@@ -182,6 +182,9 @@ struct DnBoxesArgs {
     const float *det; int attrs;          // decoded rows of ONE image [rows][attrs]
     int nheads, kind[8], grid[8], na[8], off[8];   // per head: 0 yolo / 1 region, grid size, anchors, first row
     float thresh; int w, h, netw, neth, relative;
+    // kind 2, a [detection] head (get_detection_detections, DN/detection_layer.c:225-254): every one of the side * side * num boxes,
+    // straight from the layer's input vector (= its output in inference): raw [classes | confidences | boxes]
+    const float *raw; int side, classes, sqr;
     float *rec;                           // [cap][attrs]: x, y, w, h, objectness, prob[classes]; nullptr = count only
     int *src;                             // workspace [>= cap] (row index of every kept box)
     int *count; int cap;

@@ -768,7 +768,14 @@ __global__ __launch_bounds__(1024) void k_darknet_boxes(const DnBoxesArgs a)
     __syncthreads();
     for (int hd = 0; hd < a.nheads; ++hd) {
         const int cells = a.grid[hd] * a.grid[hd], rows = cells * a.na[hd];
-        if (a.kind[hd] == 1) {
+        if (a.kind[hd] == 2) {
+            // [detection]: no selection, no reordering -- box i * num + n of the layer is record i * num + n
+            const int base = s_base;
+            for (int r = tid; r < rows; r += 1024) if (base + r < a.cap) a.src[base + r] = a.off[hd] + r;
+            __syncthreads();
+            if (tid == 0) s_base = base + rows;
+            __syncthreads();
+        } else if (a.kind[hd] == 1) {
             const int base = s_base;
             for (int r = tid; r < rows; r += 1024) {
                 const int i = r / a.na[hd], n = r - i * a.na[hd];
@@ -808,6 +815,22 @@ __global__ __launch_bounds__(1024) void k_darknet_boxes(const DnBoxesArgs a)
         const int row = a.src[rec];
         int kind = 0;
         for (int hd = 0; hd < a.nheads; ++hd) if (row >= a.off[hd]) kind = a.kind[hd];
+        if (kind == 2) {
+            // operation for operation get_detection_detections: (pred + col) / side * w in float, pow(pred, 2) * w through double
+            const int hd0 = 0, r = row - a.off[hd0], nb = a.na[hd0], i = r / nb, n = r - i * nb, side = a.side;
+            const float *pr = a.raw;
+            const float scale = pr[side * side * a.classes + i * nb + n];
+            const float *bx = pr + side * side * (a.classes + nb) + (i * nb + n) * 4;
+            float v;
+            if (k == 0) v = (bx[0] + (i % side)) / side * w;
+            else if (k == 1) v = (bx[1] + (i / side)) / side * h;
+            else if (k == 2) v = (float)(pow((double)bx[2], a.sqr ? 2 : 1) * w);
+            else if (k == 3) v = (float)(pow((double)bx[3], a.sqr ? 2 : 1) * h);
+            else if (k == 4) v = scale;
+            else { const float prob = scale * pr[i * a.classes + (k - 5)]; v = prob > a.thresh ? prob : 0.f; }
+            a.rec[idx] = v;
+            continue;
+        }
         const float *p = a.det + (size_t)row * a.attrs;
         const float obj_raw = p[4];
         const float objectness = kind == 1 ? (obj_raw > a.thresh ? obj_raw : 0.f) : obj_raw;

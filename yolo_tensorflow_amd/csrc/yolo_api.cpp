@@ -1151,10 +1151,17 @@ int yolo_darknet_boxes(yolo_ctx *c, int w, int h, float thresh, int relative, fl
     }
     DnBoxesArgs a; memset(&a, 0, sizeof a);
     a.det = c->d_det; a.attrs = c->attrs;
-    for (auto &L : c->layers) {
-        if (L.type == L_DETECT) return fail(c, YOLO_ERR_UNSUPPORTED, "[detection] heads are not served through the darknet veneer");
-        if (L.type != L_YOLO && L.type != L_REGION) continue;
+    for (size_t li = 0; li < c->layers.size(); ++li) {
+        const Layer &L = c->layers[li];
+        if (L.type != L_YOLO && L.type != L_REGION && L.type != L_DETECT) continue;
         if (a.nheads == 8) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 8 heads");
+        if (L.type == L_DETECT) {
+            if (a.nheads) return fail(c, YOLO_ERR_UNSUPPORTED, "a [detection] head next to other heads");
+            a.raw = (const float *)c->layers[li - 1].out.ptr; a.side = L.side; a.classes = L.classes; a.sqr = L.sqr;
+            a.kind[0] = 2; a.grid[0] = L.side; a.na[0] = L.na; a.off[0] = L.row_off; a.nheads = 1;
+            continue;
+        }
+        if (a.raw) return fail(c, YOLO_ERR_UNSUPPORTED, "a [detection] head next to other heads");
         a.kind[a.nheads] = L.type == L_REGION; a.grid[a.nheads] = L.H; a.na[a.nheads] = L.na; a.off[a.nheads] = L.row_off; ++a.nheads;
     }
     a.thresh = thresh; a.w = w; a.h = h; a.netw = c->in_w; a.neth = c->in_h; a.relative = relative;
@@ -1174,7 +1181,7 @@ size_t yolo_last_layer_size(const yolo_ctx *c)
     if (!c) return 0;
     for (int i = (int)c->layers.size() - 1; i >= 0; --i) {
         const Layer &L = c->layers[i];
-        if (L.type == L_DETECT) return 0;
+        if (L.type == L_DETECT) return (size_t)L.side * L.side * (L.classes + 5 * L.na);      // the layer copies its input (DN/detection_layer.c:50-57)
         if (L.type == L_YOLO || L.type == L_REGION) return (size_t)L.H * L.W * L.na * (5 + L.classes);
     }
     return 0;
@@ -1185,12 +1192,16 @@ int yolo_last_layer_output(yolo_ctx *c, float *out, size_t out_floats)
     if (!c || !out) return YOLO_ERR_INVALID;
     if (c->last_n < 1) return fail(c, YOLO_ERR_STATE, "yolo_last_layer_output before a forward pass");
     const int li = (int)c->layers.size() - 1;
-    if (li < 1 || (c->layers[li].type != L_YOLO && c->layers[li].type != L_REGION))
+    if (li < 1 || (c->layers[li].type != L_YOLO && c->layers[li].type != L_REGION && c->layers[li].type != L_DETECT))
         return fail(c, YOLO_ERR_UNSUPPORTED, "the last layer is not a detection head");
     const Layer &L = c->layers[li]; const Layer &P = c->layers[li - 1];
     const size_t need = yolo_last_layer_size(c);
     if (out_floats < need) return fail(c, YOLO_ERR_INVALID, "output buffer too small (%zu < %zu floats)", out_floats, need);
     HIPCK(c, hipSetDevice(c->device));
+    if (L.type == L_DETECT) {             // image 0's prediction vector as the fully connected layer left it (fp32, contiguous)
+        HIPCK(c, hipMemcpyAsync(out, P.out.ptr, need * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
+        return YOLO_OK;
+    }
     if (!c->d_dn_last) HIPCK(c, hipMalloc((void **)&c->d_dn_last, need * 4));
     HIPCK(c, launch_head_darknet_layout((const float *)P.out.ptr, P.out.stride, L.H * L.W, L.na, L.classes, L.type == L_REGION, c->d_dn_last, c->stream));
     HIPCK(c, hipMemcpyAsync(out, c->d_dn_last, need * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
