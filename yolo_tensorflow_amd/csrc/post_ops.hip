@@ -477,6 +477,9 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     sbox += (size_t)img * a.rows; slabel += (size_t)img * a.rows; sscore += (size_t)img * a.rows;
     BoxOut *out = (BoxOut *)a.boxes_out + (size_t)img * a.max_out;
 
+    // unused record slots read as zeros (this replaces a memset node in front of every launch); the kept boxes are written by thread
+    // 0 after later barriers
+    for (int k = tid; k < a.max_out * (int)(sizeof(BoxOut) / 4); k += NMS_THREADS) ((unsigned *)out)[k] = 0u;
     // (1) order-preserving compaction of rows whose score passes the threshold (tf.boolean_mask order)
     if (tid == 0) s_base = 0;
     __syncthreads();

@@ -645,10 +645,13 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
     p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w; p.scores_ready = scores_ready;
     p.scores = c->d_scores; p.labels = c->d_labels; p.cand = c->d_cand; p.keys = c->d_keys; p.rows_pow2 = c->rows_pow2;
     p.sbox = c->d_sbox; p.slabel = c->d_slabel; p.sscore = c->d_sscore; p.boxes_out = c->d_boxes; p.counts_out = c->d_counts;
-    HIPCK(c, hipMemsetAsync(c->d_boxes, 0, need * sizeof(yolo_box), c->stream));
+    // device-resident outputs are written by the NMS kernel itself (it also zeroes the unused slots): no memset, no copies
+    const bool direct_b = boxes_out && out_loc != YOLO_HOST, direct_c = counts_out && out_loc != YOLO_HOST;
+    if (direct_b) p.boxes_out = boxes_out;
+    if (direct_c) p.counts_out = (int *)counts_out;
     HIPCK(c, launch_postprocess(p, c->stream));
-    if (boxes_out) { int r = copy_out(c, boxes_out, c->d_boxes, need * sizeof(yolo_box), out_loc); if (r) return r; }
-    if (counts_out) { int r = copy_out(c, counts_out, c->d_counts, (size_t)n * 4, out_loc); if (r) return r; }
+    if (boxes_out && !direct_b) { int r = copy_out(c, boxes_out, c->d_boxes, need * sizeof(yolo_box), out_loc); if (r) return r; }
+    if (counts_out && !direct_c) { int r = copy_out(c, counts_out, c->d_counts, (size_t)n * 4, out_loc); if (r) return r; }
     return YOLO_OK;
 }
 
