@@ -189,3 +189,34 @@ def test_detect_skips_the_decoded_tensor_but_not_the_boxes(hiplib):
     eng.forward(img, want_detections=False)
     assert len(eng.postprocess(3, score_thr=0.3, nms_mode=hiplib.NMS_NUMPY_V3)) == 3
     eng.close()
+
+
+def test_detect_edge_thresholds_and_device_outputs(hiplib):
+    """The objectness-first lean decode and the NMS kernel's own output handling at the edges: a threshold nothing passes (counts 0,
+    every record slot zeroed even though the caller's device buffer held garbage), a threshold low enough that every box survives
+    the objectness pre-filter (the per-lane decode does all the work), each equal to forward + postprocess."""
+    import torch
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 96)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=12)
+    img = np.random.default_rng(16).integers(0, 256, (2, 96, 96, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2)
+    eng.set_weights(flat)
+    dimg = torch.from_numpy(img).cuda()
+    for thr, mo in ((0.999999, 7), (0.02, 50), (0.3, 1)):
+        eng.forward(img, want_detections=False)
+        want = eng.postprocess(2, score_thr=thr, iou_thr=0.5, max_out=mo, nms_mode=hiplib.NMS_TF)
+        boxes = torch.full((2, mo * 6), 0x7f7f7f7f, dtype=torch.int32, device="cuda"); counts = torch.full((2,), -5, dtype=torch.int32, device="cuda")
+        for _ in range(3):                                        # eager, capture, replay
+            eng.detect_graph(dimg, boxes, counts, score_thr=thr, iou_thr=0.5, max_out=mo, nms_mode=hiplib.NMS_TF)
+        eng.synchronize()
+        got_c = counts.cpu().numpy(); got = boxes.cpu().numpy().view(hiplib.BOX_DTYPE).reshape(2, mo)
+        for b in range(2):
+            assert got_c[b] == len(want[b]) <= mo
+            assert np.array_equal(got[b, :got_c[b]], want[b])
+            assert not got[b, got_c[b]:].view(np.uint8).any()     # unused slots are zero, whatever the buffer held
+        if thr > 0.9:
+            assert got_c.sum() == 0
+        if thr < 0.1:
+            assert got_c.min() > 5
+    eng.close()
+
