@@ -106,8 +106,8 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // (Tried on the free-running form and dropped, same-box A/B with tools/kslope.py, YOLOv3-416 batch-32 layer shapes: three and four
 // filter stages -- K-step 0.57 vs 0.59 us on the 13x13 layers, nothing on the others, kept as cfg 43; fragment read-ahead of 2 / 6 /
 // 8 groups instead of 4 -- +-1 %; a direct-store epilogue (v_permlane32_swap pairs, 16-B stores straight from the accumulators, no
-// LDS staging and no barrier) -- bit-identical and not one microsecond faster: the ~10 us a layer pays outside its K loop are the
-// dispatch and the prologue / epilogue HBM bursts of 256 workgroups that are all in the same phase, not the staging.)
+// LDS staging and no barrier) -- bit-identical and not one microsecond faster: what a layer pays outside its K loop is instruction
+// issue in the set-up and the epilogue (stamped builds), which that variant did not shorten.)
 // (Tried and dropped: starting half of the workgroups 3-6 us late -- by XCD parity, by CU parity inside an XCD, in four phases -- so
 // that the prologue / epilogue bursts of the two halves do not coincide.  The late half costs its full delay on every layer (26x26:
 // +2.2 us per 3 us of delay) and the early half gains < 1 us: the fixed phases are latency chains per CU, not an aggregate HBM limit.)
