@@ -460,7 +460,8 @@ def test_fused_1x1_tail_halo_forms_full_size(hiplib):
     for i, s in enumerate(secs[1:]):
         if s["type"] != "convolutional" or int(s["filters"]) not in (128, 256):
             continue
-        for cand in ((41,) if int(s["filters"]) == 128 else (40, 32)):
+        # 128-channel producers: f176c128 with two (41) and with three (43) filter stages, alternately
+        for cand in (((43, 41) if fused[128] % 2 == 0 else (41, 43)) if int(s["filters"]) == 128 else (40, 32)):
             trial = cfgs.copy(); trial[i] = cand + 10000
             try:
                 eng.set_tile_configs(trial)
