@@ -474,3 +474,33 @@ def test_fused_1x1_tail_halo_forms_full_size(hiplib):
     assert np.array_equal(eng.forward(img), want)
     eng.close()
 
+
+@pytest.mark.parametrize("cfg", ["yolov2", "yolov3-tiny", "yolov2-tiny-voc"])
+def test_halo_forms_on_the_other_topologies_full_size(hiplib, cfg):
+    """The halo-staged / free-running 3x3 forms were tuned on YOLOv3; at 416 x 416 they also apply to the 13 / 26 / 52 / 104 / 208 grids
+    of the other topologies (other channel counts: 1024 -> 1024, 3072 -> 1024 after the reorg concat, 512 -> 1024 ...).  Every layer
+    that accepts one runs it; the decoded tensor must equal the default plan's bit for bit."""
+    txt = IO.cfg_text(cfg)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=14)
+    img = np.random.default_rng(15).integers(0, 256, (2, 416, 416, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16)
+    eng.set_weights(flat)
+    want = eng.forward(img).copy()
+    cfgs = np.full(eng.num_layers, -1, np.int32)
+    used = {}
+    for i, s in enumerate(secs[1:]):
+        if s["type"] != "convolutional" or int(s["size"]) != 3:
+            continue
+        for cand in ((40, 43, 41, 36) if len(used) % 2 == 0 else (43, 41, 40, 36)):
+            trial = cfgs.copy(); trial[i] = cand
+            try:
+                eng.set_tile_configs(trial)
+                cfgs = trial; used[i] = cand
+                break
+            except hiplib.YoloError:
+                pass
+    assert len(used) >= 3, used
+    eng.set_tile_configs(cfgs)
+    assert np.array_equal(eng.forward(img), want)
+    eng.close()
+
