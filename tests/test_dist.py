@@ -86,3 +86,42 @@ def test_two_rank_flat_record_exchange():
     for i in range(world * n_local):
         want, cnt = _fake_boxes(i, max_out)
         assert gc[i] == cnt and np.array_equal(gb[i], want.view(np.int32).reshape(-1))
+
+
+def _pipe_worker(rank, world, port, n_local, max_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec, boxes, counts = ydist.alloc_flat_records(n_local, max_out, "cpu")
+    g = ydist.PipelinedGather(rec)
+    seen = []
+    for step in range(3):                                     # the library overwrites `rec` every step; each step is exchanged
+        for i in range(n_local):
+            b, cnt = _fake_boxes(100 * step + rank * n_local + i, max_out)
+            boxes[i] = torch.from_numpy(b.view(np.int32).reshape(-1)); counts[i] = cnt
+        g.submit(rec)
+        rec.zero_()                                           # the next step's compute may clobber `rec` while the gather is in flight
+        if step == 1:
+            seen.append(g.result().clone())                   # a consumer reads step 1's records before submitting step 2
+    seen.append(g.result().clone())
+    q.put((rank, [t.numpy() for t in seen]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_gather():
+    """bench.py's exchange for N > 1: copy to a staging buffer, asynchronous all-gather, waited for one step later."""
+    n_local, max_out, world = 2, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, n_local, max_out, q)) for r in range(world)]
+    for p in procs: p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for k, step in enumerate((1, 2)):
+        assert np.array_equal(results[0][k], results[1][k])
+        gb, gc = ydist.split_flat_records(torch.from_numpy(results[0][k]), n_local, max_out)
+        for i in range(world * n_local):
+            want, cnt = _fake_boxes(100 * step + i, max_out)
+            assert gc[i] == cnt and np.array_equal(gb[i].numpy(), want.view(np.int32).reshape(-1))
+

@@ -40,6 +40,14 @@ def run_check(rank, world, local_rank, n_local=4, size=160, max_out=10):
     gb = gb.cpu().numpy().view(hip.BOX_DTYPE).reshape(n_local * world, max_out); gc = gc.cpu().numpy()
     for i in range(n_local * world):
         assert gc[i] == len(want[i]) and np.array_equal(gb[i, :gc[i]], want[i]), "rank %d: image %d differs after the all-gather" % (rank, i)
+    # the pipelined form bench.py uses: staged copy + asynchronous collective, waited for one step later
+    pg = ydist.PipelinedGather(rec)
+    for _ in range(3):
+        eng.detect_graph(images, boxes, counts, score_thr=0.3, iou_thr=0.5, max_out=max_out)
+        pg.submit(rec)
+    rec_p = pg.result()
+    torch.cuda.synchronize(dev)
+    assert torch.equal(rec_p, rec_all), "rank %d: pipelined gather differs from the blocking one" % rank
     # the ragged-shard form (padded blocks) on device tensors too
     buf = torch.from_numpy(ydist.pack_records(gb[lo:hi], gc[lo:hi].astype(np.int32), max_out)).to(dev)
     full = ydist.all_gather_detections(buf, n_local * world).cpu().numpy()

@@ -87,6 +87,38 @@ def gather_flat_records(rec, out=None, group=None):
     return out
 
 
+class PipelinedGather(object):
+    """The same exchange taken off the critical path: step n's records are copied (a few KB, on the compute stream) into a staging
+    buffer and gathered from there asynchronously -- RCCL runs the collective on its own stream -- while step n+1 computes into the
+    library's output buffer again; the collective is waited for one step later, just before the staging buffer is reused.  Every
+    step is still exchanged; `result()` returns the gathered records of the last submitted step (it makes the current stream wait
+    for that collective), so a consumer sees them one step behind the compute."""
+
+    def __init__(self, rec, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.stage = torch.empty_like(rec)
+        self.out = torch.empty((self.world, rec.numel()), dtype=rec.dtype, device=rec.device)
+        self.work = None
+
+    def submit(self, rec):
+        import torch.distributed as dist
+        if self.work is not None:
+            self.work.wait()                      # stream-ordered for RCCL: the previous gather is done with `stage` / `out`
+        self.stage.copy_(rec, non_blocking=True)
+        if rec.is_cuda:
+            self.work = dist.all_gather_into_tensor(self.out, self.stage, group=self.group, async_op=True)
+        else:
+            self.work = dist.all_gather([self.out[r] for r in range(self.world)], self.stage, group=self.group, async_op=True)
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait(); self.work = None
+        return self.out
+
+
 def split_flat_records(rec_all, n_local, max_out):
     """[world, flat] -> (boxes [world*n_local, max_out*6], counts [world*n_local]) in rank (= image) order."""
     world = rec_all.shape[0]
