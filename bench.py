@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_FP8_TFLOPS = 5000.0       # dense e4m3 through v_mfma_*_f8f6f4 (same table)
+PEAK_F32_TFLOPS = 157.3        # v_mfma_f32_16x16x4_f32: exact fp32 at the vector rate (same table, "Peak FP32 (matrix)")
 
 
 def cpu_baseline(cfg_txt, flat, budget_s=25.0):
@@ -67,8 +68,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
-    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
-                    help="bf16 is BASELINE.json's headline configuration; fp8 is its config 5 (reported as a separate line)")
+    ap.add_argument("--dtype", choices=("bf16", "fp8", "fp32"), default="bf16",
+                    help="bf16 is BASELINE.json's headline configuration; fp8 is its config 5; fp32 is the exact-fp32 MFMA path, the one "
+                         "that meets north_star's IoU >= 0.999 (each reported as a separate line)")
     args = ap.parse_args()
 
     import torch
@@ -92,7 +94,9 @@ def main():
     max_out = 20
     stream = torch.cuda.current_stream(dev)
     fp8 = args.dtype == "fp8"
-    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
+    fp32 = args.dtype == "fp32"
+    peak = PEAK_FP8_TFLOPS if fp8 else PEAK_F32_TFLOPS if fp32 else PEAK_BF16_TFLOPS
+    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.FP32 if fp32 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
                      device=local_rank, stream=stream.cuda_stream)
     eng.set_weights(flat)
     # this rank's shard of the global batch (weak scaling: B images per GPU), resident in HBM
@@ -180,15 +184,18 @@ def main():
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "YOLOv3 %dx%d batch=%d per GPU, %s: conv stack + head decode + threshold + TF-NMS%s"
-                                   % (args.size, args.size, B, "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "bf16",
+                                   % (args.size, args.size, B, "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "exact fp32 (f32 MFMA)" if fp32 else "bf16",
                                       " + RCCL all-gather of box records" if G > 1 else ""),
                        "global_batch": B * G, "input": "uint8 NHWC resident in HBM", "weights": "seeded synthetic darknet stream (seed 0)",
-                       "parallelism": "dp%d" % G},
+                       "parallelism": "dp%d" % G if G == 1 else
+                                      "dp%d; the box-record all-gather of step n runs under the compute of step n+1 (dist.PipelinedGather): "
+                                      "p50_ms_* are per-step compute on rank 0 and EXCLUDE the exchange, value / ms_per_step include every "
+                                      "exchange (the last one is waited for inside the timed region)" % G},
             "p50_ms_per_image": round(float(np.median(step_ms)) / B, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), 4), "traffic": traffic,
-                         "kernel": "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "kernel": "conv_igemm_f32 (every conv launch of one forward)" if fp32 else "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
         if G == 1 and not args.no_cpu_baseline:

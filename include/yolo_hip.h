@@ -165,6 +165,14 @@ int yolo_darknet_boxes(yolo_ctx *ctx, int w, int h, float thresh, int relative, 
  * activations applied (DN/yolo_layer.c:143-152, DN/region_layer.c:160-186).  host buffer of yolo_last_layer_size() floats. */
 size_t yolo_last_layer_size(const yolo_ctx *ctx);
 int yolo_last_layer_output(yolo_ctx *ctx, float *out, size_t out_floats);
+/* The same for images 0..n-1 of the last forward, image after image (darknet's net->output is batch * outputs contiguous floats,
+ * DN/network.c:497-508 with l.output sized batch * l.outputs, DN/yolo_layer.c:50): out holds n * yolo_last_layer_size() floats. */
+int yolo_last_layer_output_batch(yolo_ctx *ctx, int n, float *out, size_t out_floats);
+
+/* The raw tensor detection head `head` (0-based, cfg order) decodes, for images 0..n-1 of the last forward: the head conv's fp32
+ * output [n, grid, grid, anchors * (5 + classes)] dense, to host -- what the reference's graph builders return before any decode
+ * (`build_network` V2/model_darknet19_slim.py:198-200; the per-scale `predictions` of V3/yolo_v3.py:239-263). */
+int yolo_head_raw(yolo_ctx *ctx, int head, int n, float *out, size_t out_floats);
 
 /* Threshold + NMS on the resident decoded tensor of the last forward (rows S, N1/N3).
  * boxes_out: [n * max_out] caller-owned, counts_out: [n]; both at out_loc.
@@ -172,6 +180,13 @@ int yolo_last_layer_output(yolo_ctx *ctx, float *out, size_t out_floats);
  * V3/YOLOV3.py:347-379. */
 int yolo_postprocess(yolo_ctx *ctx, int n, float score_thr, float iou_thr, int max_out,
                      int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int out_loc);
+
+/* The same, and for every box record the ROW of the decoded tensor it was formed from (0 .. yolo_num_rows()-1 within its image):
+ * rows_out [n * max_out] int32 at out_loc, -1 in the unused slots; NULL = not reported.  `self.boxes` of the reference's detectors
+ * is the decoded row itself (V1/YOLO_V1_Inference.py:255-268 gathers `_boxes` with the NMS indices): the index is what
+ * tf.image.non_max_suppression returns, mapped back through the threshold mask. */
+int yolo_postprocess_rows(yolo_ctx *ctx, int n, float score_thr, float iou_thr, int max_out,
+                          int nms_mode, int select_mode, yolo_box *boxes_out, int32_t *counts_out, int32_t *rows_out, int out_loc);
 
 /* forward + postprocess. */
 int yolo_detect(yolo_ctx *ctx, const void *images, int n, int fmt, int loc, float scale,
@@ -236,6 +251,10 @@ int yolo_op_nms_detections(const float *boxes_xywh, float *prob, float *objectne
 int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr,
                         int max_out, int nms_mode, int select_mode, yolo_box *boxes_out,
                         int32_t *counts_out, int device);
+/* ... with the source row of every record (see yolo_postprocess_rows); rows_out [n * max_out] host, or NULL */
+int yolo_op_postprocess_rows(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr,
+                             int max_out, int nms_mode, int select_mode, yolo_box *boxes_out,
+                             int32_t *counts_out, int32_t *rows_out, int device);
 
 #ifdef __cplusplus
 }

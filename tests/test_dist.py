@@ -39,11 +39,15 @@ def _worker(rank, world, port, B, max_out, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_rank_gather_matches_single_process():
-    B, max_out, world = 7, 5, 2          # ragged split 4 + 3
+import pytest
+
+
+@pytest.mark.parametrize("B,world", [(7, 2), (30, 4)])      # ragged splits: 4 + 3; 8 + 8 + 7 + 7 (batch not a multiple of the GPU count)
+def test_gather_matches_single_process(B, world):
+    max_out = 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = 29500 + (os.getpid() + 17 * world) % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, max_out, q)) for r in range(world)]
     for p in procs: p.start()
     results = dict(q.get(timeout=120) for _ in range(world))
@@ -101,8 +105,10 @@ def _pipe_worker(rank, world, port, n_local, max_out, q):
         g.submit(rec)
         rec.zero_()                                           # the next step's compute may clobber `rec` while the gather is in flight
         if step == 1:
-            seen.append(g.result().clone())                   # a consumer reads step 1's records before submitting step 2
+            held = g.result()                                 # a consumer takes step 1's records and KEEPS the tensor (no copy) across
+                                                              # the next submit: the buffers alternate, so step 2's gather must not touch it
     seen.append(g.result().clone())
+    seen.insert(0, held.clone())
     q.put((rank, [t.numpy() for t in seen]))
     dist.barrier(); dist.destroy_process_group()
 

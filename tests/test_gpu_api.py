@@ -110,13 +110,18 @@ def test_yolo_v2_entry_points(hiplib):
     x = yolo_v2.preprocess_image(img, (size, size))
     want_x = R.resize_bilinear_legacy(img.astype(np.float32) / np.float32(255), size, size) * np.float32(255.0 / 225.0)
     np.testing.assert_allclose(x[0], want_x, rtol=0, atol=2e-6)
-    out = yolo_v2.build_network(x, model=m)
     g = size // 32
+    raw = yolo_v2.build_network(x, model=m)                      # the reference's contract: the raw head (V2/model_darknet19_slim.py:198-200)
+    assert raw.shape == (1, g, g, 425)
+    out = yolo_v2.build_network(x, model=m, fused=True)          # the device's fused form: decoded rows
     assert out.shape == (1, g * g * 5, 85)
     osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
     heads, _ = R.forward(osecs, params, x)
+    np.testing.assert_allclose(raw, heads[0][1], rtol=2e-3, atol=2e-3 * float(np.abs(heads[0][1]).max()))
     rb, ro, rc = R.region_decode(heads[0][1], np.array(yolo_v2.anchors, np.float32), 80)
-    bboxes, obj, cls = yolo_v2.decode(out, output_sizes=(g, g), num_class=80)
+    bboxes, obj, cls = yolo_v2.decode(raw, output_sizes=(g, g), num_class=80)
+    for got, fused in zip((bboxes, obj, cls), yolo_v2.decode(out, output_sizes=(g, g), num_class=80)):
+        assert np.array_equal(got, fused)                        # decode(raw head) == decode(fused rows): the same region kernel on the same fp32 tensor
     assert bboxes.shape == (1, g * g, 5, 4) and obj.shape == (1, g * g, 5) and cls.shape == (1, g * g, 5, 80)
     np.testing.assert_allclose(bboxes, rb, rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(obj, ro, rtol=2e-3, atol=2e-3)
@@ -220,3 +225,56 @@ def test_detect_edge_thresholds_and_device_outputs(hiplib):
             assert got_c.min() > 5
     eng.close()
 
+
+
+def test_postprocess_rows_and_graph_replay_state(hiplib):
+    """(1) yolo_postprocess_rows: every record's row index points at the decoded row it was formed from (all NMS flavours);
+    (2) ADVICE r02: forward(A) -> detect_graph replay on B -> postprocess must see image B's state (here: the replay went through the
+    lean decode, so a flavour that needs the decoded tensor is refused, and the TF flavour equals detect(B)) -- never A's stale tensor."""
+    import torch
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 160)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=2)
+    rng = np.random.default_rng(61)
+    A = rng.integers(0, 256, (2, 160, 160, 3), dtype=np.uint8); B = rng.integers(0, 256, (2, 160, 160, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2)
+    eng.set_weights(flat)
+    det = eng.forward(A)
+    for mode in (hiplib.NMS_TF, hiplib.NMS_DARKNET, hiplib.NMS_NUMPY_V3):
+        recs, rows = eng.postprocess(2, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=mode, return_rows=True)
+        plain = eng.postprocess(2, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=mode)
+        assert sum(len(r) for r in recs) > 6
+        for b in range(2):
+            assert np.array_equal(recs[b], plain[b]) and len(rows[b]) == len(recs[b])
+            d = det[b][rows[b]]
+            if mode == hiplib.NMS_DARKNET:
+                want = d[:, :4]
+            else:
+                h = np.float32(0.5)
+                want = np.stack([d[:, 0] - d[:, 2] * h, d[:, 1] - d[:, 3] * h, d[:, 0] + d[:, 2] * h, d[:, 1] + d[:, 3] * h], -1)
+            got = np.stack([recs[b]["x0"], recs[b]["y0"], recs[b]["x1"], recs[b]["y1"]], -1)
+            assert np.array_equal(got, want)
+            if mode != hiplib.NMS_NUMPY_V3:       # (that flavour reports shifted scores, V3/yolo_v3.py:414-418)
+                assert np.array_equal(recs[b]["score"], (d[:, 4:5] * d[:, 5:]).max(-1))
+                assert np.array_equal(recs[b]["cls"], (d[:, 4:5] * d[:, 5:]).argmax(-1))
+    # single-operator form
+    recs, rows = hiplib.op_postprocess(det, 0.3, 0.45, 25, return_rows=True)
+    for b in range(2):
+        assert np.array_equal(recs[b]["score"], (det[b][rows[b], 4:5] * det[b][rows[b], 5:]).max(-1))
+    # ---- graph replay leaves the context in the state of the call it replays ----
+    dB = torch.from_numpy(B).cuda()
+    boxes = torch.zeros((2, 25 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    for _ in range(3):                              # eager, capture, replay
+        eng.detect_graph(dB, boxes, counts, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=hiplib.NMS_TF)
+    eng.synchronize()
+    wantB = eng.detect(B, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=hiplib.NMS_TF)
+    eng.forward(A)                                  # det_valid = True, decoded tensor of A resident
+    eng.detect_graph(dB, boxes, counts, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=hiplib.NMS_TF)      # replay on B
+    eng.synchronize()
+    got = eng.postprocess(2, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=hiplib.NMS_TF)
+    for b in range(2):
+        assert np.array_equal(got[b], wantB[b])     # B's boxes with B's scores -- not A's stale geometry
+    with pytest.raises(hiplib.YoloError, match="without materialising"):
+        eng.postprocess(2, score_thr=0.3, nms_mode=hiplib.NMS_NUMPY_V3)
+    with pytest.raises(hiplib.YoloError, match="lower threshold"):
+        eng.postprocess(2, score_thr=0.1, nms_mode=hiplib.NMS_TF)
+    eng.close()

@@ -172,6 +172,14 @@ def test_make_network_boxes_and_batch(pair):
     b2, o2, p2 = _collect(d2, n2.value, 80)
     assert n2.value == n0.value and np.array_equal(b2, b0) and np.array_equal(o2, o0) and np.array_equal(p2, p0)
     ven.free_detections(d2, n2.value)
+    # net->output of a batch is batch * outputs contiguous floats (DN/network.c:497-508): every image's head, not just the first
+    # (the reference's set_batch_network does not re-allocate a batch-1 network's buffers, so its two outputs come from two batch-1 calls)
+    outs = (size // 16) ** 2 * 255                                            # last [yolo] layer of yolov3-tiny: the stride-16 head
+    want = np.stack([np.ctypeslib.as_array(ref.network_predict(rnet, two[b].ctypes.data_as(C.POINTER(C.c_float))), shape=(outs,)).copy() for b in range(2)])
+    v_out = ven.network_predict(vnet, two.ctypes.data_as(C.POINTER(C.c_float)))
+    got = np.ctypeslib.as_array(v_out, shape=(2, outs)).copy()
+    assert not np.array_equal(want[0], want[1])
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
     ven.set_batch_network(vnet, 1)
 
 

@@ -21,6 +21,7 @@ struct network {
     std::vector<float> out;              // last layer's output in darknet layout (what network_predict returns)
     std::vector<float> rec;              // get_network_boxes staging: [count][5 + classes]
     bool have = false;
+    int fwd_n = 1;                       // images of the last forward (network_predict: batch; network_predict_image: 1)
 };
 
 namespace {
@@ -59,14 +60,14 @@ bool open_ctx(network *net)
     }
     yolo_input_size(net->ctx, &net->h, &net->w, nullptr);
     net->rows = yolo_num_rows(net->ctx); net->attrs = yolo_num_attrs(net->ctx);
-    net->out.assign(yolo_last_layer_size(net->ctx), 0.f);
+    net->out.assign(yolo_last_layer_size(net->ctx) * (size_t)net->batch, 0.f);      // net->output: batch * outputs floats
     net->have = false;
     return true;
 }
 
 float *fetch_output(network *net)
 {
-    net->have = yolo_last_layer_output(net->ctx, net->out.data(), net->out.size()) == YOLO_OK;
+    net->have = yolo_last_layer_output_batch(net->ctx, net->fwd_n, net->out.data(), net->out.size()) == YOLO_OK;
     if (!net->have) { fprintf(stderr, "darknet_hip: %s\n", yolo_last_error(net->ctx)); return nullptr; }
     return net->out.data();
 }
@@ -102,14 +103,15 @@ void set_batch_network(network *net, int b)
     yolo_destroy(prev);
 }
 
-// `input`: batch x planar [3][h][w] at network size.  Returns the last layer's output of the FIRST image (net->output), see
-// include/darknet_hip.h.
+// `input`: batch x planar [3][h][w] at network size.  Returns net->output: the last layer's output of every image of the batch,
+// image after image (batch * outputs floats, DN/network.c:497-508), see include/darknet_hip.h.
 float *network_predict(network *net, float *input)
 {
     if (!net || !input) return nullptr;
     if (yolo_forward(net->ctx, input, net->batch, YOLO_IMG_F32_CHW, YOLO_HOST, 1.0f, nullptr, YOLO_HOST) != YOLO_OK) {
         net->have = false; fprintf(stderr, "darknet_hip: %s\n", yolo_last_error(net->ctx)); return nullptr;
     }
+    net->fwd_n = net->batch;
     return fetch_output(net);
 }
 
@@ -119,6 +121,7 @@ float *network_predict_image(network *net, image im)
     if (yolo_forward_letterbox_chw(net->ctx, im.data, im.w, im.h, YOLO_HOST, nullptr, YOLO_HOST) != YOLO_OK) {
         net->have = false; fprintf(stderr, "darknet_hip: %s\n", yolo_last_error(net->ctx)); return nullptr;
     }
+    net->fwd_n = 1;
     return fetch_output(net);
 }
 

@@ -173,6 +173,9 @@ struct PostArgs {
     float *scores; int *labels; int *cand; unsigned long long *keys; int rows_pow2;
     float4 *sbox; int *slabel; float *sscore;
     void *boxes_out; int *counts_out;   // yolo_box [n*max_out], int [n] (device)
+    // optional: the decoded-tensor row (0 .. rows-1, within its image) every kept record came from, [n*max_out], -1 in unused slots;
+    // needs the workspace srow [n*rows].  nullptr: not reported
+    int *rows_out; int *srow;
 };
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);
 hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *out, int out_dt, int out_stride, hipStream_t s);

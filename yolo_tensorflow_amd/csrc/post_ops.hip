@@ -480,6 +480,9 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     // unused record slots read as zeros (this replaces a memset node in front of every launch); the kept boxes are written by thread
     // 0 after later barriers
     for (int k = tid; k < a.max_out * (int)(sizeof(BoxOut) / 4); k += NMS_THREADS) ((unsigned *)out)[k] = 0u;
+    int *const rows_out = a.rows_out ? a.rows_out + (size_t)img * a.max_out : nullptr;
+    int *const srow = a.rows_out ? a.srow + (size_t)img * a.rows : nullptr;      // row of every sorted candidate
+    if (rows_out) for (int k = tid; k < a.max_out; k += NMS_THREADS) rows_out[k] = -1;
     // (1) order-preserving compaction of rows whose score passes the threshold (tf.boolean_mask order)
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -554,6 +557,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
             b = float4{(float)x0, (float)y0, (float)x1, (float)y1};
         }
         sbox[i] = b; slabel[i] = labels[row]; sscore[i] = scores[row];
+        if (srow) srow[i] = row;
     }
     for (int i = tid; i < 1024; i += NMS_THREADS) {
         int lo = i * 32;
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
                 const float4 bh = sbox[head];
                 const int kept = s_kept;
                 if (tid == 0) {
-                    if (kept < a.max_out) out[kept] = BoxOut{bh.x, bh.y, bh.z, bh.w, sscore[head], slabel[head]};
+                    if (kept < a.max_out) { out[kept] = BoxOut{bh.x, bh.y, bh.z, bh.w, sscore[head], slabel[head]}; if (rows_out) rows_out[kept] = srow[head]; }
                     s_kept = kept + 1;
                     atomicAnd(&alive[head >> 5], ~(1u << (head & 31)));
                 }
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
         const float4 bc = sbox[cur];
         const int lc = slabel[cur];
         if (tid == 0) {
-            if (kept < a.max_out) out[kept] = BoxOut{bc.x, bc.y, bc.z, bc.w, sscore[cur], lc};
+            if (kept < a.max_out) { out[kept] = BoxOut{bc.x, bc.y, bc.z, bc.w, sscore[cur], lc}; if (rows_out) rows_out[kept] = srow[cur]; }
             s_kept = kept + 1;
         }
         for (int j = cur + 1 + tid; j < M; j += NMS_THREADS) {

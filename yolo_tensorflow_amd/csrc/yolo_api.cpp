@@ -92,8 +92,9 @@ struct yolo_ctx {
     float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
     void *d_boxes = nullptr; int *d_counts = nullptr; int boxes_cap = 0;
+    int *d_srow = nullptr, *d_rows = nullptr;      // rows_out support: row of every sorted candidate [max_batch * rows], staging [boxes_cap]
     // darknet-flavoured outputs (yolo_darknet_boxes / yolo_last_layer_output): records, row list, count, last layer's planar output
-    float *d_dn_rec = nullptr; int *d_dn_src = nullptr; int *d_dn_count = nullptr; float *d_dn_last = nullptr;
+    float *d_dn_rec = nullptr; int *d_dn_src = nullptr; int *d_dn_count = nullptr; float *d_dn_last = nullptr; size_t dn_last_cap = 0;
     // yolo_detect_graph state
     struct GKey { const void *img; int n, fmt; float scale, st, it; int mo, nm, sm; void *bo, *co; } gkey{};
     hipGraphExec_t gexec = nullptr; int gstate = 0;      // 0: next call eager, 1: next call captures, 2: replay, -1: capture unsupported
@@ -344,7 +345,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             if (j >= NL) continue;
             Layer &T = c->layers[j];
             if (T.type == L_CONV && !T.fc && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
-                T.residual_from < -1 && !T.stem_tail) { P.tail_layer = j; T.fused_into = i; }
+                T.residual_from < -1 && !T.stem_tail && T.in_dt == P.in_dt) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
         }
     }
     // storage assignment: st_of[i] = storage holding layer i's output
@@ -492,7 +493,9 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
-    if (L.tail_on && L.tail_layer >= 0) {
+    // the tail runs on the producer's operand type: bf16 needs the fragment-order copy of the 1x1 filters (tail_fragments), e4m3 an
+    // e4m3-packed 1x1 conv; anything else leaves w2 null and run_layer refuses the plan instead of launching with a null w2f
+    if (L.tail_on && L.tail_layer >= 0 && c->layers[L.tail_layer].in_dt == L.in_dt && (L.in_dt == DT_FP8 || c->layers[L.tail_layer].d_wf)) {
         const Layer &T = c->layers[L.tail_layer];
         a.w2 = T.d_w; a.w2f = T.d_wf; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
         a.oscale2 = T.d_sc; a.out2_inv_scale = T.out.dt == DT_FP8 ? 1.f / c->eff_scale[L.tail_layer] : 1.f;
@@ -535,6 +538,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             break;
         }
         ConvArgs a = conv_args(c, L, n);
+        if (L.tail_on && !a.w2) return fail(c, YOLO_ERR_STATE, "layer %d: the plan folds the 1x1 conv %d into this layer, but its filters are not available in the producer's operand type", i, L.tail_layer);
         if (L.s2d7) HIPCK(c, launch_reorg(nview(c->input), nview(c->s2d), 2, 0, s));      // tf.space_to_depth order: (dy, dx, channel)
         if (L.halo) {          // small-Cin 3x3: input tile staged once in LDS (conv_stem.hip)
             HaloArgs h; memset(&h, 0, sizeof h);
@@ -626,7 +630,7 @@ int copy_out(yolo_ctx *c, void *dst, const void *src, size_t bytes, int loc)
 }
 
 int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out,
-         int nms_mode, int select_mode, int img_h, int img_w, int scores_ready, yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+         int nms_mode, int select_mode, int img_h, int img_w, int scores_ready, yolo_box *boxes_out, int32_t *counts_out, int out_loc, int32_t *rows_out = nullptr)
 {
     if (max_out < 1) return fail(c, YOLO_ERR_INVALID, "max_out < 1");
     if (nms_mode < 0 || nms_mode > 4 || select_mode < 0 || select_mode > 1) return fail(c, YOLO_ERR_INVALID, "bad nms/select mode");
@@ -637,9 +641,11 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
         if (c->gstate > 0) c->gstate = 0;
         HIPCK(c, hipStreamSynchronize(c->stream));
         if (c->d_boxes) HIPCK(c, hipFree(c->d_boxes));
-        c->d_boxes = nullptr; c->boxes_cap = 0;
-        HIPCK(c, hipMalloc(&c->d_boxes, need * sizeof(yolo_box))); c->boxes_cap = (int)need;
+        if (c->d_rows) HIPCK(c, hipFree(c->d_rows));
+        c->d_boxes = nullptr; c->d_rows = nullptr; c->boxes_cap = 0;
+        HIPCK(c, hipMalloc(&c->d_boxes, need * sizeof(yolo_box))); HIPCK(c, hipMalloc((void **)&c->d_rows, need * 4)); c->boxes_cap = (int)need;
     }
+    if (rows_out && !c->d_srow) HIPCK(c, hipMalloc((void **)&c->d_srow, (size_t)c->max_batch * c->rows * 4));
     PostArgs p; memset(&p, 0, sizeof p);
     p.det = det; p.box4 = (det == c->d_det && !c->det_valid) ? c->d_box4 : nullptr; p.n = n; p.rows = rows; p.attrs = attrs; p.score_thr = score_thr; p.iou_thr = iou_thr; p.max_out = max_out;
     p.nms_mode = nms_mode; p.select_mode = select_mode; p.img_h = img_h; p.img_w = img_w; p.scores_ready = scores_ready;
@@ -649,7 +655,9 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
     const bool direct_b = boxes_out && out_loc != YOLO_HOST, direct_c = counts_out && out_loc != YOLO_HOST;
     if (direct_b) p.boxes_out = boxes_out;
     if (direct_c) p.counts_out = (int *)counts_out;
+    if (rows_out) { p.srow = c->d_srow; p.rows_out = out_loc != YOLO_HOST ? (int *)rows_out : c->d_rows; }
     HIPCK(c, launch_postprocess(p, c->stream));
+    if (rows_out && out_loc == YOLO_HOST) { int r = copy_out(c, rows_out, c->d_rows, need * 4, out_loc); if (r) return r; }
     if (boxes_out && !direct_b) { int r = copy_out(c, boxes_out, c->d_boxes, need * sizeof(yolo_box), out_loc); if (r) return r; }
     if (counts_out && !direct_c) { int r = copy_out(c, counts_out, c->d_counts, (size_t)n * 4, out_loc); if (r) return r; }
     return YOLO_OK;
@@ -780,7 +788,7 @@ void yolo_destroy(yolo_ctx *c)
     for (void *p : c->phys) if (p) hipFree(p);
     for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); if (L.d_wf) hipFree(L.d_wf); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
-                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr};
+                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr, c->d_srow, c->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1084,8 +1092,8 @@ int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h
     return YOLO_OK;
 }
 
-int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
-                     yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+int yolo_postprocess_rows(yolo_ctx *c, int n, float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
+                          yolo_box *boxes_out, int32_t *counts_out, int32_t *rows_out, int out_loc)
 {
     if (!c) return YOLO_ERR_INVALID;
     if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "postprocess of %d images but the last forward ran %d", n, c->last_n);
@@ -1098,7 +1106,13 @@ int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max
     const int ready = c->scores_mode == want;
     c->scores_mode = want;
     return post(c, c->d_det, n, c->rows, c->attrs, score_thr, iou_thr, max_out, nms_mode, select_mode,
-                nms_mode == YOLO_NMS_PER_CLASS ? c->in_h : 0, nms_mode == YOLO_NMS_PER_CLASS ? c->in_w : 0, ready, boxes_out, counts_out, out_loc);
+                nms_mode == YOLO_NMS_PER_CLASS ? c->in_h : 0, nms_mode == YOLO_NMS_PER_CLASS ? c->in_w : 0, ready, boxes_out, counts_out, out_loc, rows_out);
+}
+
+int yolo_postprocess(yolo_ctx *c, int n, float score_thr, float iou_thr, int max_out, int nms_mode, int select_mode,
+                     yolo_box *boxes_out, int32_t *counts_out, int out_loc)
+{
+    return yolo_postprocess_rows(c, n, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, nullptr, out_loc);
 }
 
 int yolo_detect(yolo_ctx *c, const void *images, int n, int fmt, int loc, float scale, float score_thr, float iou_thr,
@@ -1136,6 +1150,9 @@ int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float sca
         c->gstate = 2;
     }
     HIPCK(c, hipGraphLaunch(c->gexec, c->stream));
+    // the replay leaves the context exactly as the eager call it was captured from would (run_network / forward_impl): a later
+    // yolo_postprocess / yolo_darknet_boxes must see that the decoded tensor was (not) written and which threshold pruned the scores
+    c->lean = nms_mode != YOLO_NMS_NUMPY_V3 && c->lean_ok; c->det_valid = !c->lean; c->lean_thr = score_thr;
     c->last_n = n; c->scores_mode = nms_mode == YOLO_NMS_NUMPY_V3 ? 1 : 0;
     return YOLO_OK;
 }
@@ -1190,25 +1207,56 @@ size_t yolo_last_layer_size(const yolo_ctx *c)
     return 0;
 }
 
-int yolo_last_layer_output(yolo_ctx *c, float *out, size_t out_floats)
+int yolo_last_layer_output_batch(yolo_ctx *c, int n, float *out, size_t out_floats)
 {
     if (!c || !out) return YOLO_ERR_INVALID;
     if (c->last_n < 1) return fail(c, YOLO_ERR_STATE, "yolo_last_layer_output before a forward pass");
+    if (n < 1 || n > c->last_n) return fail(c, YOLO_ERR_INVALID, "yolo_last_layer_output of %d images but the last forward ran %d", n, c->last_n);
     const int li = (int)c->layers.size() - 1;
     if (li < 1 || (c->layers[li].type != L_YOLO && c->layers[li].type != L_REGION && c->layers[li].type != L_DETECT))
         return fail(c, YOLO_ERR_UNSUPPORTED, "the last layer is not a detection head");
     const Layer &L = c->layers[li]; const Layer &P = c->layers[li - 1];
-    const size_t need = yolo_last_layer_size(c);
+    const size_t per = yolo_last_layer_size(c), need = per * (size_t)n;
     if (out_floats < need) return fail(c, YOLO_ERR_INVALID, "output buffer too small (%zu < %zu floats)", out_floats, need);
     HIPCK(c, hipSetDevice(c->device));
-    if (L.type == L_DETECT) {             // image 0's prediction vector as the fully connected layer left it (fp32, contiguous)
-        HIPCK(c, hipMemcpyAsync(out, P.out.ptr, need * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
+    if (L.type == L_DETECT) {             // the prediction vectors as the fully connected layer left them (fp32, one "pixel" of P.out.stride floats per image)
+        HIPCK(c, hipMemcpy2DAsync(out, per * 4, P.out.ptr, (size_t)P.out.stride * 4, per * 4, (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
         return YOLO_OK;
     }
-    if (!c->d_dn_last) HIPCK(c, hipMalloc((void **)&c->d_dn_last, need * 4));
-    HIPCK(c, launch_head_darknet_layout((const float *)P.out.ptr, P.out.stride, L.H * L.W, L.na, L.classes, L.type == L_REGION, c->d_dn_last, c->stream));
+    if (!c->d_dn_last || c->dn_last_cap < need) {
+        if (c->d_dn_last) { HIPCK(c, hipStreamSynchronize(c->stream)); HIPCK(c, hipFree(c->d_dn_last)); c->d_dn_last = nullptr; c->dn_last_cap = 0; }
+        HIPCK(c, hipMalloc((void **)&c->d_dn_last, need * 4)); c->dn_last_cap = need;
+    }
+    const size_t cells = (size_t)L.H * L.W;
+    for (int b = 0; b < n; ++b)
+        HIPCK(c, launch_head_darknet_layout((const float *)P.out.ptr + (size_t)b * cells * P.out.stride, P.out.stride, (int)cells, L.na, L.classes, L.type == L_REGION, c->d_dn_last + (size_t)b * per, c->stream));
     HIPCK(c, hipMemcpyAsync(out, c->d_dn_last, need * 4, hipMemcpyDeviceToHost, c->stream)); HIPCK(c, hipStreamSynchronize(c->stream));
     return YOLO_OK;
+}
+
+int yolo_last_layer_output(yolo_ctx *c, float *out, size_t out_floats) { return yolo_last_layer_output_batch(c, 1, out, out_floats); }
+
+// The raw tensor a detection head decodes: the head conv's fp32 output [n, grid, grid, anchors * (5 + classes)] (what the reference's
+// graph builders return before any decode: V2/model_darknet19_slim.py:198-200, V3/yolo_v3.py:239-263 `predictions`).
+int yolo_head_raw(yolo_ctx *c, int head, int n, float *out, size_t out_floats)
+{
+    if (!c || !out || head < 0) return YOLO_ERR_INVALID;
+    if (c->last_n < 1 || n < 1 || n > c->last_n) return fail(c, YOLO_ERR_STATE, "yolo_head_raw of %d images but the last forward ran %d", n, c->last_n);
+    int k = 0;
+    for (size_t li = 1; li < c->layers.size(); ++li) {
+        const Layer &L = c->layers[li];
+        if (L.type != L_YOLO && L.type != L_REGION && L.type != L_DETECT) continue;
+        if (k++ != head) continue;
+        const Layer &P = c->layers[li - 1];
+        const size_t px = (size_t)n * P.H * P.W, need = px * P.C;
+        if (out_floats < need) return fail(c, YOLO_ERR_INVALID, "output buffer too small (%zu < %zu floats)", out_floats, need);
+        if (P.out.dt != DT_F32 || !P.out.ptr) return fail(c, YOLO_ERR_STATE, "internal: head conv output is not fp32");
+        HIPCK(c, hipSetDevice(c->device));
+        HIPCK(c, hipMemcpy2DAsync(out, (size_t)P.C * 4, P.out.ptr, (size_t)P.out.stride * 4, (size_t)P.C * 4, px, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        return YOLO_OK;
+    }
+    return fail(c, YOLO_ERR_INVALID, "no detection head %d", head);
 }
 
 int yolo_synchronize(yolo_ctx *c) { if (!c) return YOLO_ERR_INVALID; HIPCK(c, hipStreamSynchronize(c->stream)); return YOLO_OK; }
@@ -1385,7 +1433,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int i = 0; i < NL; ++i) {
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
-                bool ok = conv_cfg_tail_ok(cfg, L.filters, c->dtype == YOLO_FP8);
+                bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8) && c->layers[L.tail_layer].in_dt == L.in_dt;
                 if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo13_ok(a); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
@@ -1432,7 +1480,7 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
         int v = cfgs[i]; bool tail = false;
         if (v >= 10000) { v -= 10000; tail = true; }
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
-        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->dtype == YOLO_FP8)))
+        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->layers[i].in_dt == DT_FP8) || c->layers[c->layers[i].tail_layer].in_dt != c->layers[i].in_dt))
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
         if (tail && conv_cfg_is_halo(v)) {
             ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
@@ -1612,8 +1660,8 @@ int yolo_op_nms_detections(const float *boxes_xywh, float *prob, float *objectne
     return S.download(objectness, d_o, (size_t)n * 4);
 }
 
-int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out, int nms_mode,
-                        int select_mode, yolo_box *boxes_out, int32_t *counts_out, int device)
+int yolo_op_postprocess_rows(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out, int nms_mode,
+                             int select_mode, yolo_box *boxes_out, int32_t *counts_out, int32_t *rows_out, int device)
 {
     if (!det || !boxes_out || !counts_out || n < 1 || rows < 1 || rows > 32768 || attrs < 6 || max_out < 1) return YOLO_ERR_INVALID;
     OpScope S(device); if (S.rc) return S.rc;
@@ -1627,10 +1675,18 @@ int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float scor
     p.keys = (unsigned long long *)S.alloc((size_t)n * p2 * 8); p.rows_pow2 = p2;
     p.sbox = (float4 *)S.alloc(nr * 16); p.slabel = (int *)S.alloc(nr * 4); p.sscore = (float *)S.alloc(nr * 4);
     p.boxes_out = S.alloc((size_t)n * max_out * sizeof(yolo_box)); p.counts_out = (int *)S.alloc((size_t)n * 4);
+    if (rows_out) { p.srow = (int *)S.alloc(nr * 4); p.rows_out = (int *)S.alloc((size_t)n * max_out * 4); }
     if (S.rc) return S.rc;
     if (!S.ok(launch_postprocess(p, S.s))) { g_op_err = S.err; return S.rc; }
     S.download(boxes_out, p.boxes_out, (size_t)n * max_out * sizeof(yolo_box));
+    if (rows_out) S.download(rows_out, p.rows_out, (size_t)n * max_out * 4);
     return S.download(counts_out, p.counts_out, (size_t)n * 4);
+}
+
+int yolo_op_postprocess(const float *det, int n, int rows, int attrs, float score_thr, float iou_thr, int max_out, int nms_mode,
+                        int select_mode, yolo_box *boxes_out, int32_t *counts_out, int device)
+{
+    return yolo_op_postprocess_rows(det, n, rows, attrs, score_thr, iou_thr, max_out, nms_mode, select_mode, boxes_out, counts_out, nullptr, device);
 }
 
 }  // extern "C"

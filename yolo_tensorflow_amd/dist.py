@@ -90,33 +90,45 @@ def gather_flat_records(rec, out=None, group=None):
 class PipelinedGather(object):
     """The same exchange taken off the critical path: step n's records are copied (a few KB, on the compute stream) into a staging
     buffer and gathered from there asynchronously -- RCCL runs the collective on its own stream -- while step n+1 computes into the
-    library's output buffer again; the collective is waited for one step later, just before the staging buffer is reused.  Every
-    step is still exchanged; `result()` returns the gathered records of the last submitted step (it makes the current stream wait
-    for that collective), so a consumer sees them one step behind the compute."""
+    library's output buffer again; the collective is waited for one step later.  Every step is still exchanged; `result()` returns
+    the gathered records of the last submitted step (it makes the current stream wait for that collective), so a consumer sees them
+    one step behind the compute.
+
+    Staging and output buffers are DOUBLE-BUFFERED (alternating per submit): the tensor `result()` returns is not touched by the
+    next `submit()`, only by the one after it -- a consumer may keep reading it (on the current stream, or after a stream sync on
+    the host) while the next step's collective is in flight."""
 
     def __init__(self, rec, group=None):
         import torch
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
-        self.stage = torch.empty_like(rec)
-        self.out = torch.empty((self.world, rec.numel()), dtype=rec.dtype, device=rec.device)
-        self.work = None
+        self.stage = [torch.empty_like(rec) for _ in range(2)]
+        self.out = [torch.empty((self.world, rec.numel()), dtype=rec.dtype, device=rec.device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0            # buffer pair the NEXT submit uses
+        self.last = None      # buffer pair of the last submit
 
     def submit(self, rec):
         import torch.distributed as dist
-        if self.work is not None:
-            self.work.wait()                      # stream-ordered for RCCL: the previous gather is done with `stage` / `out`
-        self.stage.copy_(rec, non_blocking=True)
+        k = self.k
+        if self.work[k] is not None:
+            self.work[k].wait(); self.work[k] = None      # the gather that used this pair two submits ago (stream-ordered for RCCL)
+        self.stage[k].copy_(rec, non_blocking=True)
         if rec.is_cuda:
-            self.work = dist.all_gather_into_tensor(self.out, self.stage, group=self.group, async_op=True)
+            self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
         else:
-            self.work = dist.all_gather([self.out[r] for r in range(self.world)], self.stage, group=self.group, async_op=True)
+            self.work[k] = dist.all_gather([self.out[k][r] for r in range(self.world)], self.stage[k], group=self.group, async_op=True)
+        self.last = k; self.k = 1 - k
 
     def result(self):
-        if self.work is not None:
-            self.work.wait(); self.work = None
-        return self.out
+        """Gathered records [world, len(rec)] of the last submitted step; valid until the submit after the next one."""
+        if self.last is None:
+            return None
+        k = self.last
+        if self.work[k] is not None:
+            self.work[k].wait(); self.work[k] = None
+        return self.out[k]
 
 
 def split_flat_records(rec_all, n_local, max_out):

@@ -30,6 +30,7 @@ EXPORTS = [
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_darknet_boxes", "yolo_last_layer_size", "yolo_last_layer_output", "yolo_op_letterbox",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
+    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw",
 ]
 
 
@@ -98,6 +99,10 @@ def load_library():
     l.yolo_last_layer_output.argtypes = [P, P, C.c_size_t]
     l.yolo_op_letterbox.argtypes = [P, I, I, I, I, I, P, I]
     l.yolo_op_postprocess.argtypes = [P, I, I, I, F, F, I, I, I, P, P, I]
+    l.yolo_op_postprocess_rows.argtypes = [P, I, I, I, F, F, I, I, I, P, P, P, I]
+    l.yolo_postprocess_rows.argtypes = [P, I, F, F, I, I, I, P, P, P, I]
+    l.yolo_last_layer_output_batch.argtypes = [P, I, P, C.c_size_t]
+    l.yolo_head_raw.argtypes = [P, I, I, P, C.c_size_t]
     _lib = l
     return l
 
@@ -242,17 +247,39 @@ class Engine:
         return det
 
     def postprocess(self, n, score_thr=0.5, iou_thr=0.5, max_out=20, nms_mode=NMS_TF, select_mode=SELECT_GT,
-                    boxes_out=None, counts_out=None):
-        """-> list of structured arrays (BOX_DTYPE) per image, or writes into the given device buffers."""
+                    boxes_out=None, counts_out=None, rows_out=None, return_rows=False):
+        """-> list of structured arrays (BOX_DTYPE) per image, or writes into the given device buffers.
+        return_rows=True: -> (records, rows) where rows[i] holds, for every kept record of image i, the row of the decoded tensor
+        it was formed from (yolo_postprocess_rows); rows_out: the same into a device int32 buffer [n * max_out]."""
         if boxes_out is not None:
-            bp, bloc = _ptr(boxes_out); cp, _ = _ptr(counts_out)
-            self._order_after_producer(boxes_out, counts_out)
-            self._check(self.lib.yolo_postprocess(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode, bp, cp, bloc), "yolo_postprocess")
+            bp, bloc = _ptr(boxes_out); cp, _ = _ptr(counts_out); rp, _ = _ptr(rows_out)
+            self._order_after_producer(boxes_out, counts_out, rows_out)
+            self._check(self.lib.yolo_postprocess_rows(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode, bp, cp, rp, bloc), "yolo_postprocess")
             return None
         boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)
-        self._check(self.lib.yolo_postprocess(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode,
-                                              boxes.ctypes.data, counts.ctypes.data, HOST), "yolo_postprocess")
-        return [boxes[i, :counts[i]].copy() for i in range(n)]
+        rows = np.full((n, max_out), -1, dtype=np.int32) if return_rows else None
+        self._check(self.lib.yolo_postprocess_rows(self.ctx, n, score_thr, iou_thr, max_out, nms_mode, select_mode,
+                                                   boxes.ctypes.data, counts.ctypes.data, rows.ctypes.data if return_rows else None, HOST), "yolo_postprocess")
+        recs = [boxes[i, :counts[i]].copy() for i in range(n)]
+        if return_rows:
+            return recs, [rows[i, :counts[i]].copy() for i in range(n)]
+        return recs
+
+    def head_raw(self, head, n):
+        """Raw fp32 tensor [n, grid, grid, anchors * (5 + classes)] that detection head `head` decodes (yolo_head_raw)."""
+        kind, grid, na, off = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.yolo_head_geometry(self.ctx, head, C.byref(kind), C.byref(grid), C.byref(na), C.byref(off)), "yolo_head_geometry")
+        out = np.empty((n, grid.value, grid.value, na.value * self.attrs), dtype=np.float32)
+        self._check(self.lib.yolo_head_raw(self.ctx, head, n, out.ctypes.data, out.size), "yolo_head_raw")
+        return out
+
+    def last_layer_output(self, n=1):
+        """darknet's net->output (DN/network.c:497-508) of images 0..n-1 of the last forward: [n, yolo_last_layer_size()] float32."""
+        self.lib.yolo_last_layer_size.restype = C.c_size_t
+        per = self.lib.yolo_last_layer_size(self.ctx)
+        out = np.empty((n, per), dtype=np.float32)
+        self._check(self.lib.yolo_last_layer_output_batch(self.ctx, n, out.ctypes.data, out.size), "yolo_last_layer_output_batch")
+        return out
 
     def detect(self, images, scale=1.0 / 255.0, **kw):
         self.forward(images, scale=scale, want_detections=False)
@@ -390,8 +417,10 @@ def op_decode(raw, anchors, classes, img_size, decode=DECODE_RATIO, region=False
     return out
 
 
-def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mode=SELECT_GT, image_hw=None, corners=False, device=0):
-    """det [n,rows,5+C] fp32 rows (cx,cy,w,h,obj,cls..) -- or (x0,y0,x1,y1,obj,cls..) with corners=True."""
+def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mode=SELECT_GT, image_hw=None, corners=False, device=0,
+                   return_rows=False):
+    """det [n,rows,5+C] fp32 rows (cx,cy,w,h,obj,cls..) -- or (x0,y0,x1,y1,obj,cls..) with corners=True.
+    return_rows=True: -> (records, rows): the row of `det` every kept record was formed from."""
     det = _f32(det); n, rows, attrs = det.shape
     mode = nms_mode
     if corners:
@@ -399,6 +428,11 @@ def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mod
     if image_hw is not None:
         mode |= (int(image_hw[0]) << 8) | (int(image_hw[1]) << 20)
     boxes = np.zeros((n, max_out), dtype=BOX_DTYPE); counts = np.zeros(n, dtype=np.int32)
-    _op_check(load_library().yolo_op_postprocess(det.ctypes.data, n, rows, attrs, score_thr, iou_thr, max_out, mode, select_mode,
-                                                 boxes.ctypes.data, counts.ctypes.data, device), "yolo_op_postprocess")
-    return [boxes[i, :counts[i]].copy() for i in range(n)]
+    ridx = np.full((n, max_out), -1, dtype=np.int32) if return_rows else None
+    _op_check(load_library().yolo_op_postprocess_rows(det.ctypes.data, n, rows, attrs, score_thr, iou_thr, max_out, mode, select_mode,
+                                                      boxes.ctypes.data, counts.ctypes.data, ridx.ctypes.data if return_rows else None, device),
+              "yolo_op_postprocess")
+    recs = [boxes[i, :counts[i]].copy() for i in range(n)]
+    if return_rows:
+        return recs, [ridx[i, :counts[i]].copy() for i in range(n)]
+    return recs

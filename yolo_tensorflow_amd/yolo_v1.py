@@ -50,21 +50,13 @@ class Yolo(object):
         image = np.ascontiguousarray(image, dtype=np.uint8)
         img_h, img_w, _ = image.shape
         det = self.engine.forward_image(image)[0]                       # [S*S*B, 5 + C] rows (cx, cy, w, h, conf, cls...)
-        kept = self.engine.postprocess(1, score_thr=self.threshold, iou_thr=self.iou_threshold, max_out=self.max_output_size,
-                                       nms_mode=hip.NMS_TF_V1, select_mode=hip.SELECT_GE)[0]
+        kept, rows = self.engine.postprocess(1, score_thr=self.threshold, iou_thr=self.iou_threshold, max_out=self.max_output_size,
+                                             nms_mode=hip.NMS_TF_V1, select_mode=hip.SELECT_GE, return_rows=True)
+        kept, rows = kept[0], rows[0].astype(np.int64)
         # the records carry the corners the reference hands to tf.image.non_max_suppression (horizontal extent from h, vertical from
-        # w); `self.boxes` of the reference is the decoded (cx, cy, w, h) row itself: identify each record's row by those corners
+        # w); `self.boxes` of the reference is the decoded (cx, cy, w, h) row itself, gathered with the NMS indices (:264-268): the
+        # library reports that row index with every record (yolo_postprocess_rows)
         f = np.float32
-        x0 = det[:, 0] - f(0.5) * det[:, 3]; y0 = det[:, 1] - f(0.5) * det[:, 2]
-        x1 = det[:, 0] + f(0.5) * det[:, 3]; y1 = det[:, 1] + f(0.5) * det[:, 2]
-        sc = (det[:, 4:5] * det[:, 5:]).max(-1)
-        rows = []
-        for r in kept:
-            m = np.nonzero((x0 == r["x0"]) & (y0 == r["y0"]) & (x1 == r["x1"]) & (y1 == r["y1"]) & (sc == r["score"]))[0]
-            if len(m) == 0:
-                raise hip.YoloError("internal: a kept box does not match any decoded row")
-            rows.append(int(m[0]))
-        rows = np.asarray(rows, dtype=np.int64)
         scores = kept["score"].copy(); box_classes = kept["cls"].astype(np.int64)
         boxes = det[rows, :4].copy() if len(rows) else np.zeros((0, 4), np.float32)
         boxes[:, 0] *= f(1.0 * img_w); boxes[:, 1] *= f(1.0 * img_h); boxes[:, 2] *= f(1.0 * img_w); boxes[:, 3] *= f(1.0 * img_h)

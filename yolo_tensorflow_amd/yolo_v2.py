@@ -32,21 +32,43 @@ def preprocess_image(image, image_size=(416, 416)):
     return hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0], post_scale=255.0 / 225.0)[None]
 
 
-def build_network(images, num_outputs=425, alpha=0.1, keep_prob=0.5, is_training=False, scope='yolov2', model=None):
-    """V2/model_darknet19_slim.py:119: images [N,416,416,3] already normalised -> the decoded head.  The reference
-    returns the raw [N,13,13,425] tensor and decodes in a second graph; the device fuses both, so this returns the
-    decoded rows [N, 845, 85] = (bx, by, bw, bh, objectness, softmax classes) that `decode` consumes."""
+def build_network(images, num_outputs=425, alpha=0.1, keep_prob=0.5, is_training=False, scope='yolov2', model=None, fused=False):
+    """V2/model_darknet19_slim.py:119-200: images [N,416,416,3] already normalised -> the RAW head tensor [N,13,13,num_outputs]
+    (the `logits` of :198-200), which `decode` consumes and which a caller may inspect or save (the freeze script
+    V2/yOLO_v2_export_graph.py does).  fused=True returns the device's fused result instead -- the decoded rows [N, 845, 85] =
+    (bx, by, bw, bh, objectness, softmax classes) -- which `decode` accepts as well (one host copy less)."""
     if model is None:
         raise hip.YoloError("pass model=yolo_v2.Model(weights_file=...)")
-    return model.engine.forward(np.ascontiguousarray(images, dtype=np.float32), scale=1.0)
+    images = np.ascontiguousarray(images, dtype=np.float32)
+    if fused:
+        return model.engine.forward(images, scale=1.0)
+    model.engine.forward(images, scale=1.0, want_detections=False)
+    raw = model.engine.head_raw(0, images.shape[0])
+    if raw.shape[-1] != num_outputs:
+        raise hip.YoloError("the topology's head has %d outputs per cell, num_outputs=%d was asked for" % (raw.shape[-1], num_outputs))
+    return raw
+
+
+def _decoded_rows(model_output, output_sizes, num_class, anchors_):
+    """raw head [N,H,W,A*(5+C)] -> decoded rows [N, H*W*A, 5+C] with the region decode kernel (V2/decode.py:13-47); rows pass through."""
+    d = np.asarray(model_output, dtype=np.float32)
+    if d.ndim == 3:
+        return d
+    if d.ndim != 4 or d.shape[1] != output_sizes[0] or d.shape[2] != output_sizes[1] or d.shape[1] != d.shape[2]:
+        raise hip.YoloError("decode: expected the raw head [N,%d,%d,A*(5+C)] or decoded rows [N,rows,5+C]" % tuple(output_sizes))
+    a = np.asarray(anchors if anchors_ is None else anchors_, dtype=np.float32)
+    if d.shape[3] != len(a) * (5 + num_class):
+        raise hip.YoloError("decode: head depth %d does not match %d anchors x (5 + %d)" % (d.shape[3], len(a), num_class))
+    return hip.op_decode(d, a, num_class, 32 * output_sizes[0], region=True)
 
 
 def decode(model_output, output_sizes=(13, 13), num_class=80, threshold=None, iou_threshold=0.5, anchors=None, model=None):
     """Two reference functions share this name:
        V2/decode.py:13      decode(model_output, output_sizes, num_class, anchors) -> (bboxes, obj_probs, class_probs)
        V2/postprocess.py:10 decode(..., threshold=0.5, iou_threshold=0.5, anchors) -> (boxes, scores, classes) after TF NMS (max 10)
-    `model_output` is what build_network returned.  threshold=None selects the first form."""
-    d = np.asarray(model_output, dtype=np.float32)
+    `model_output` is what build_network returned: the raw head [N,13,13,425] (decoded here by the region kernel) or, from
+    build_network(fused=True), the already decoded rows.  threshold=None selects the first form."""
+    d = _decoded_rows(model_output, output_sizes, num_class, anchors)
     n = d.shape[0]
     H, W = output_sizes
     A = d.shape[1] // (H * W)
