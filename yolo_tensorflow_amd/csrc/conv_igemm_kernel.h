@@ -78,7 +78,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { st
 // and of lanes {4-11} of a 16-lane MFMA column group are distinct mod 8; kHaloPerm13 (tools/gen/halo_perm.py) assigns the
 // block's pixels to MFMA columns accordingly (raster order would conflict two-way in every group).
 // lane -> pixel assignment for a 13x13 block, generated by tools/gen/halo_perm.py (worst conflict degree 2, one group)
-__device__ const unsigned short kHaloPerm13[176] = {
+constexpr unsigned short kHaloPerm13[176] = {
     0x0000, 0x0101, 0x0202, 0x0303, 0x0808, 0x0909, 0x0a0a, 0x0b0b, 0x0c0c, 0x1313, 0x1414, 0x0d0d, 0x0404, 0x0505, 0x0606, 0x0707,
     0x0e0e, 0x0f0f, 0x1010, 0x1111, 0x1616, 0x1717, 0x1818, 0x1919, 0x2020, 0x2727, 0x2222, 0x1b1b, 0x1212, 0x2121, 0x1a1a, 0x1515,
     0x1c1c, 0x1d1d, 0x1e1e, 0x1f1f, 0x2424, 0x2525, 0x2626, 0x2d2d, 0x3434, 0x3535, 0x3030, 0x2929, 0x2e2e, 0x2f2f, 0x2828, 0x2323,
@@ -91,6 +91,22 @@ __device__ const unsigned short kHaloPerm13[176] = {
     0x8c8c, 0x8d8d, 0x8e8e, 0x9595, 0x9292, 0x9393, 0x9494, 0xa3a3, 0xa4a4, 0xa5a5, 0x9e9e, 0x9999, 0x9c9c, 0x9d9d, 0x9898, 0x9191,
     0x9a9a, 0x9b9b, 0xa2a2, 0xa8a8, 0xa0a0, 0xa1a1, 0xab02, 0xac03, 0xad04, 0xae05, 0xaf06, 0xa7a7, 0xa904, 0xaa05, 0xa6a6, 0x9f9f,
 };
+// The same table as a lane reads it: 32 bytes per l15 = two 16-byte loads issued with the kernel's first instructions (bytes 0..10: the
+// pixel whose window sub-tile j's lane reads; bytes 16..26: the row of the output tile it writes).  (Eleven byte loads per table
+// sat behind the prologue's LDS-DMA in the in-order vmcnt queue: their first use waited for the whole prologue to land.)
+struct HaloPermPk { unsigned w[16][8]; };
+constexpr HaloPermPk make_halo_perm_pk()
+{
+    HaloPermPk t{};
+    for (int l = 0; l < 16; ++l)
+        for (int j = 0; j < 11; ++j) {
+            const unsigned v = kHaloPerm13[j * 16 + l];
+            t.w[l][j / 4] |= (v & 0xffu) << (8 * (j % 4));
+            t.w[l][4 + j / 4] |= (v >> 8) << (8 * (j % 4));
+        }
+    return t;
+}
+__device__ const HaloPermPk kHaloPermPk = make_halo_perm_pk();
 constexpr int HALO_B = 13;                         // block edge (output pixels)
 constexpr int HALO_P = HALO_B + 2;                 // halo pitch and height (input pixels)
 constexpr int HALO_APIX = 160;                     // bytes of one halo pixel record in LDS
@@ -162,6 +178,16 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_top)::"memory");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // halo form: this lane's slice of the pixel permutation, requested before anything else (it is independent of the arguments)
+    u32x4_t perm_rd = {0, 0, 0, 0}, perm_wr = {0, 0, 0, 0};
+    if constexpr (HALO) {
+        const u32x4_t *pk = (const u32x4_t *)kHaloPermPk.w[lane & 15];
+        perm_rd = pk[0]; perm_wr = pk[1];
+    }
+    // the arguments the way to the first LDS-DMA needs, as ONE burst of scalar loads (left alone the compiler fetches each field
+    // right before its first use: a dozen dependent scalar-cache round trips in front of the prologue)
+    asm volatile("" ::"s"(a.in), "s"(a.wt), "s"(a.in_stride), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.Kpad), "s"(a.Ho), "s"(a.Wo),
+                 "s"(a.tc_mul), "s"(a.tc_shift), "s"(a.bpi_mul), "s"(a.bpi_shift), "s"(a.bpr_mul), "s"(a.bpr_shift));
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_loader = NL == 0 || wave_id >= NC;          // wave-uniform role
     // deliberately a run-time value even when NL == 0 (always true then): with the branch folded away the scheduler
@@ -203,6 +229,21 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int chunk = BK == 64 ? ((lane & 7) ^ (rl & 7)) : ((lane & 3) ^ (3 * ((rl >> 2) & 1)));
     const int KK = a.ksize * a.ksize;
     const int HoWo = a.Ho * a.Wo;
+    unsigned woff[LB > 0 ? LB : 1];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int crow = (FREE ? wid * LB + i : wid + i * NW) * RG + rl;
+        woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * EPC) * (unsigned)EB : OOB_OFFSET;
+    }
+    // K-step 0's filter rows are requested first -- their offsets are the cheapest to form, and the pixel addressing below (halo form:
+    // ~130 instructions; tiled form: ~55 per row group) then runs while they are in flight.  Order in the vmcnt queue: filters of step 0,
+    // activations of step 0, later stages: the counted waits of the K loop only rely on whole K-steps retiring in order.
+    if (is_loader && 0 < a.Kpad / BKE) {
+        char *const f0 = smem + (HALO ? 2 * HALO_ACT_BYTES : BPL * RB);
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(f0 + (FREE ? wid * LB + i : wid + i * NW) * 1024), 16, woff[i], 0, 0, 0);
+    }
     unsigned rowoff[LA];                       // byte offset of tap (0,0), channel chunk*8 (UNI) or 0 (per-lane tap)
     unsigned tapmask[LA];                      // bit t set: tap t of this pixel lies inside the image
     // halo form: per-lane source offsets of this wave's halo pieces.  LDS slot g = piece * 64 + lane holds 16-B piece g % 10 of
@@ -222,7 +263,21 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // The CPRW lanes that fill one LDS row all need the same (offset, tap mask) pair for each of the wave's LA row groups: lane q of
     // such a lane group works out row group q (+ CPRW per pass) only, and the group exchanges the results with ds_bpermute -- one
     // evaluation per lane instead of LA (this setup is ~55 instructions per row; it was a third of a short layer's fixed cost).
-    if constexpr (!HALO) {
+    // 1x1 / stride 1 / pad 0 (a third of the launches): output pixel m IS input pixel m and its one tap is always inside the image --
+    // no divisions, no exchange (wave-uniform branch)
+    const bool pointwise = !HALO && a.ksize == 1 && a.stride == 1 && a.pad == 0;
+    if (!HALO && pointwise) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int prow = (wid + i * NW) * RG + rl;
+            const int m = pt * BP + prow;
+            const bool ok = m < M && prow < BP;
+            // (the descriptor base sits (W + 1) pixels before the tensor, see `shift`)
+            rowoff[i] = (unsigned)((m + a.W + 1) * a.in_stride) * (unsigned)EB + (UNI ? (unsigned)(chunk * EPC * EB) : 0u);
+            tapmask[i] = ok ? 1u : 0u;
+        }
+    }
+    if (!HALO && !pointwise) {
         const int q = lane % CPRW;
 #pragma unroll
         for (int p0 = 0; p0 < LA; p0 += CPRW) {
@@ -264,12 +319,6 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             }
         }
     }
-    unsigned woff[LB > 0 ? LB : 1];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int crow = (FREE ? wid * LB + i : wid + i * NW) * RG + rl;
-        woff[i] = crow < BC ? (unsigned)((ct * BC + crow) * a.Kpad + chunk * EPC) * (unsigned)EB : OOB_OFFSET;
-    }
 
     // K cursor.  UNI: scalars (tap, kh, kw, channel base).  Otherwise per lane (chunk-dependent).
     int s_tap = 0, s_kh = 0, s_kw = 0, s_kb = 0, s_cb = 0;   // UNI: tap, its (kh, kw), channel offset in the chunk, chunk base
@@ -277,7 +326,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if (!UNI)
         while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
     int s_wk = 0;                                       // byte offset of the K-step in a filter row
-    auto stage = [&](char *sbase) {
+    auto stage = [&](char *sbase, const bool with_w = true) {
         char *dx = sbase + wid * 1024;
         char *dw = sbase + BPL * RB + wid * 1024;
         if (UNI) {
@@ -316,9 +365,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             v_kc += BKE;
             while (v_kc >= a.Cin_pad) { v_kc -= a.Cin_pad; ++v_tap; }
         }
+        if (with_w) {
 #pragma unroll
-        for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dw + i * NW * 1024), 16, woff[i], s_wk, 0, 0);
+            for (int i = 0; i < LB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dw + i * NW * 1024), 16, woff[i], s_wk, 0, 0);
+        }
         s_wk += RB;
     };
 
@@ -347,7 +398,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             for (int i = 0; i < LAH; ++i)
                 if (wid + i * NW < APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(smem + (wid + i * NW) * 1024), 16, aoff[i], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < (FREE ? NS - 1 : 1); ++t)
+            for (int t = 1; t < (FREE ? NS - 1 : 1); ++t)        // (stage 0 was requested ahead of the halo addressing)
                 if (t < KT) {
 #pragma unroll
                     for (int i = 0; i < LB; ++i)
@@ -358,7 +409,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     } else {
 #pragma unroll
         for (int t = 0; t < D; ++t)
-            if (t < KT && is_loader) stage(smem + t * STAGE_BYTES);
+            if (t < KT && is_loader) stage(smem + t * STAGE_BYTES, t != 0);      // (step 0's filters were requested ahead of the addressing)
     }
 
     const int l15 = lane & 15, lq = lane >> 4;
@@ -372,7 +423,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     if constexpr (HALO) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            const int p = kHaloPerm13[j * 16 + l15] & 0xff;
+            const int p = (int)((perm_rd[j / 4] >> (8 * (j % 4))) & 0xffu);
             const int y = p / HB, x = p - y * HB;
             abase[j] = (y * HP + x) * APIX + lq * 16;
         }
@@ -667,18 +718,28 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         int prow[HALO ? TP : 1];
         if constexpr (HALO) {
 #pragma unroll
-            for (int j = 0; j < TP; ++j) prow[j] = (kHaloPerm13[j * 16 + l15] >> 8) * RS;      // byte offset of the row in the LDS tile
+            for (int j = 0; j < TP; ++j) prow[j] = (int)((perm_wr[j / 4] >> (8 * (j % 4))) & 0xffu) * RS;      // byte offset of the row in the LDS tile
+        }
+        // bias (and the fp8 dequantisation scale) of this lane's channels: requested before the barrier, which covers their latency
+        f32x4 bvs[TC], svs[TC];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int chl = (wci * TC + i) * 16 + lq * 4;
+            bvs[i] = is_consumer ? *(const f32x4 *)(a.bias + ct * BC + chl) : f32x4{0.f, 0.f, 0.f, 0.f};
+            svs[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (EB == 1 && a.oscale && is_consumer) svs[i] = *(const f32x4 *)(a.oscale + ct * BC + chl);
         }
         block_barrier();                                      // every wave is done reading the last stage
         if (DIAG) te1 = stamp();
+        // (Tried and dropped, round 3: converting the accumulators to packed bf16 in registers BEFORE this barrier, so that only the LDS
+        // writes remain behind it.  The stamped build moved 1 300 cycles in front of the barrier and took 100 off the phase behind it: that
+        // phase is the LDS store path -- 176 ds_write_b64 per wave pair at ~12 cycles each -- not the arithmetic; the step got 1.7 % slower.)
         const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
         if (is_consumer)
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
-            const f32x4 bv = *(const f32x4 *)(a.bias + ct * BC + chl);
-            f32x4 sv = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (EB == 1 && a.oscale) sv = *(const f32x4 *)(a.oscale + ct * BC + chl);
+            const f32x4 bv = bvs[i], sv = svs[i];
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 f32x4 v = acc[i][j];
