@@ -978,6 +978,17 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             const float4 bv = *(const float4 *)(a.bias + ch);
             float4 sv = float4{1.f, 1.f, 1.f, 1.f};
             if (EB == 1 && a.oscale) sv = *(const float4 *)(a.oscale + ch);
+            // [yolo] head: is one of this lane's four channels a box's objectness logit (channel an * (5 + classes) + 4)?  Those are also
+            // written to a compact plane [pixel][anchor] -- the decode's objectness pre-filter then reads 12 bytes per cell in one
+            // coalesced stream instead of one 128-byte line per box out of this tensor
+            int oq = -1, oan = 0;
+            if (a.obj_out) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int an = fast_div(ch + q, a.obj_mul, a.obj_shift);
+                    if (ch + q - an * a.obj_attrs == 4 && ch + q < a.Cout) { oq = q; oan = an; }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const int m = pt * BP + (wpi * TP + j) * 16 + l15;
@@ -990,6 +1001,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
                 }
                 float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
+                if (oq >= 0) a.obj_out[(size_t)m * a.obj_na + oan] = oq == 0 ? v[0] : oq == 1 ? v[1] : oq == 2 ? v[2] : v[3];
                 if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
                 else
                     for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];

@@ -49,6 +49,9 @@ struct ConvArgs {
     const void *zeros;                   // >= 64 B of zeros in device memory (padding source)
     // n / d for n < 2^31 as mulhi(n, mul) >> shift (shift == 255: d == 1); filled by conv_finalize()
     uint32_t howo_mul, howo_shift, wo_mul, wo_shift;
+    // fp32 head convs feeding a [yolo] layer: objectness logits (channel an * obj_attrs + 4 of every pixel) are ALSO written to
+    // obj_out[pixel * obj_na + an]; nullptr: off.  obj_mul / obj_shift: division by obj_attrs (conv_magic)
+    float *obj_out; int obj_attrs, obj_na; uint32_t obj_mul, obj_shift;
     unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
     // division constants of the tile decode, filled by the launcher for its tile shape (conv_tile_magic): channel tiles per pixel
     // tile; halo form: 13x13 blocks per image and per block row
@@ -155,6 +158,17 @@ struct DecodeArgs {
                                         // (score = objectness * class probability <= objectness): its class work is skipped and its
                                         // score is reported as the objectness itself.  -inf: every box is scored
 };
+// Lean decode of up to four [yolo] heads in ONE launch (yolo_detect*: the decodes of a three-scale network are three short,
+// latency-bound launches otherwise; the head tensors keep their own buffers, so the early heads can wait for the last one)
+struct LeanHead { const float *raw; const float *obj; int raw_stride, g, na, row_off; long box_begin; float anchors[2 * 16]; };      // obj: compact objectness-logit plane [n * g * g][na] written by the head conv, or nullptr (read from raw)
+struct LeanArgs {
+    int nheads; LeanHead h[4];
+    long total;                          // boxes of all heads: n * sum(g * g * na)
+    int n, classes, img_size, mode, rows_total;
+    float *box4; float reject_below;
+    uint4 *list; unsigned *list_count; unsigned list_cap;      // boxes that pass the objectness pre-filter (descriptor each); list_count[0] = entries, [1] = phase-2 workgroups done (both zero between launches)
+};
+hipError_t launch_decode_lean(const LeanArgs &a, float *scores, int *labels, hipStream_t s);
 // scores/labels (nullable): per-row max_k(obj*cls_k) and its first argmax, written alongside the decode
 hipError_t launch_decode(const DecodeArgs &a, float *scores, int *labels, hipStream_t s);
 // YOLOv1 [detection] head (row D1): raw [n][raw_stride] fp32 = [cls S*S*C | conf S*S*B | box S*S*B*4] -> det rows (cx, cy, w, h, conf, cls...)
@@ -176,6 +190,7 @@ struct PostArgs {
     // optional: the decoded-tensor row (0 .. rows-1, within its image) every kept record came from, [n*max_out], -1 in unused slots;
     // needs the workspace srow [n*rows].  nullptr: not reported
     int *rows_out; int *srow;
+    unsigned *zero_word;                // optional: a device word this launch resets to 0 (the lean decode's list counter)
 };
 hipError_t launch_postprocess(const PostArgs &a, hipStream_t s);
 hipError_t launch_letterbox_chw(const float *img, int iw, int ih, int S, void *out, int out_dt, int out_stride, hipStream_t s);

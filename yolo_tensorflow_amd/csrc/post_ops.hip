@@ -288,6 +288,127 @@ __global__ __launch_bounds__(256) void k_decode_yolo_lean(const DecodeArgs a, fl
     }
 }
 
+// The same for every head of the network in one launch, with a cooperative second phase.  Phase 1 as above (one lane per box reads
+// the objectness logit).  Phase 2: the boxes that remain are taken four at a time, one per 16-lane row of the wave: the row reads the
+// box's 5 + C attributes as coalesced 64-byte runs (the lane-per-box loop walked 340 bytes per lane, 85 dependent-address loads each,
+// with the other lanes of the wave idle), scores them, and reduces maximum and first arg-max inside the row with DPP row operations.
+// Same arithmetic per element as k_decode_yolo_lean, same first-maximum label: bit-identical scores, labels and boxes.
+__device__ __forceinline__ float row_max_dpp(float v)         // maximum over the 16 lanes of a DPP row, in every lane of the row
+{
+#define DPP_MAXR(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false)))
+    DPP_MAXR(0xB1); DPP_MAXR(0x4E); DPP_MAXR(0x124); DPP_MAXR(0x128);
+#undef DPP_MAXR
+    return v;
+}
+__device__ __forceinline__ int row_min_dpp(int v)
+{
+#define DPP_MINR(ctrl) v = min(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false))
+    DPP_MINR(0xB1); DPP_MINR(0x4E); DPP_MINR(0x124); DPP_MINR(0x128);
+#undef DPP_MINR
+    return v;
+}
+// Phase 1: one lane per box.  Boxes below the threshold are settled here; the others are appended to a list (one atomic per wave) that
+// phase 2 spreads over the whole chip -- the passing boxes cluster (an anchor, an image), and a wave that had to finish its own 64
+// boxes four at a time was the kernel's tail: 49 us for 14 000 boxes, 5 us without them.
+__global__ __launch_bounds__(1024) void k_decode_yolo_lean_p1(const LeanArgs a, float *scores, int *labels)
+{
+    __shared__ unsigned wcnt[16], s_base;
+    const int attrs = 5 + a.classes;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 1024; base < a.total; base += (long)gridDim.x * 1024) {      // (block-uniform trip count: barriers inside)
+        const long box = base + threadIdx.x;
+        const bool valid = box < a.total;
+        int hd = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (k < a.nheads && box >= a.h[k].box_begin) hd = k;
+        // per-lane head parameters (the four heads' descriptors sit in the kernel arguments: scalar selects)
+        const float *raw = a.h[0].raw, *objp = a.h[0].obj; int raw_stride = a.h[0].raw_stride, g = a.h[0].g, na = a.h[0].na, row_off = a.h[0].row_off; long bb = a.h[0].box_begin;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (hd == k) { raw = a.h[k].raw; objp = a.h[k].obj; raw_stride = a.h[k].raw_stride; g = a.h[k].g; na = a.h[k].na; row_off = a.h[k].row_off; bb = a.h[k].box_begin; }
+        const int gg = g * g;
+        const unsigned ubox = valid ? (unsigned)(box - bb) : 0u;
+        const unsigned cidx = ubox / (unsigned)na; const int an = (int)(ubox - cidx * (unsigned)na);      // cell index over n * g * g
+        const unsigned b = cidx / (unsigned)gg; const int cell = (int)(cidx - b * (unsigned)gg);
+        const unsigned row = b * (unsigned)a.rows_total + (unsigned)row_off + (unsigned)cell * (unsigned)na + (unsigned)an;
+        const unsigned eoff = cidx * (unsigned)raw_stride + (unsigned)(an * attrs);              // element offset of the box in its head tensor
+        // (the head conv leaves the objectness logits in a compact plane as well: consecutive lanes read consecutive floats)
+        const float obj = sigmoid_fast(objp ? objp[ubox] : raw[eoff + 4]);
+        const bool pass = valid && !(obj < a.reject_below);
+        if (valid && !pass) { scores[row] = obj; labels[row] = 0; }
+        // one atomic per WORKGROUP and step (all of them hit one word: ~11 ns each, whoever issues them): wave counts through LDS
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) wcnt[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned pre = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const unsigned cnt = wcnt[k]; if (k < wv) pre += cnt; tot += cnt; }
+        if (threadIdx.x == 0 && tot) s_base = atomicAdd(a.list_count, tot);
+        __syncthreads();
+        const unsigned slot = s_base + pre + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        // cell < 2^24 (grid <= 4096), anchor < 16, head < 4
+        if (pass && slot < a.list_cap) a.list[slot] = uint4{eoff, row, (unsigned)cell | ((unsigned)an << 24) | ((unsigned)hd << 28), __float_as_uint(obj)};
+    }
+}
+// Phase 2: one 16-lane row per listed box, grid-stride.  The row reads the box's 5 + C attributes as coalesced 64-byte runs, all loads
+// issued before the first use, scores them and reduces maximum and first arg-max inside the row with DPP row operations -- the same
+// arithmetic per element as k_decode_yolo_lean, the same first-maximum label: bit-identical scores, labels and boxes.  
+__global__ __launch_bounds__(256) void k_decode_yolo_lean_p2(const LeanArgs a, float *scores, int *labels)
+{
+    const int attrs = 5 + a.classes;
+    const int l15 = threadIdx.x & 15;
+    const unsigned rowid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, nrows = (gridDim.x * blockDim.x) >> 4;
+    unsigned count = __hip_atomic_load(a.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count > a.list_cap) count = a.list_cap;
+    for (unsigned base = 0; base < count; base += nrows) {               // (uniform trip count: the DPP reductions want whole rows)
+        const unsigned idx = base + rowid;
+        const bool act = idx < count;
+        const uint4 d = act ? a.list[idx] : uint4{0, 0, 0, 0};
+        const unsigned r_eoff = d.x, r_row = d.y; const int r_cell = (int)(d.z & 0xffffffu), r_an = (int)((d.z >> 24) & 15u), r_hd = (int)(d.z >> 28);
+        const float r_obj = __uint_as_float(d.w);
+        const float *r_raw = a.h[0].raw; int r_g = a.h[0].g;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (r_hd == k) { r_raw = a.h[k].raw; r_g = a.h[k].g; }
+        const float *src = r_raw + r_eoff;
+        float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int k = l15 + 16 * t; vv[t] = (act && k < attrs) ? src[k] : 0.f; }
+        const float g_raw = vv[0];
+        float best = -INFINITY; int label = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                                    // ascending k inside a lane: a strict > keeps the first maximum
+            const int k = l15 + 16 * t;
+            if (act && k >= 5 && k < attrs) { const float sc = r_obj * sigmoid_fast(vv[t]); if (sc > best) { best = sc; label = k - 5; } }
+        }
+        const float rbest = row_max_dpp(best);
+        const int rlabel = row_min_dpp(best == rbest ? label : 0x7fffffff);      // lowest class index holding the maximum
+        if (act && l15 < 4) {
+            const int stride = a.img_size / r_g;
+            const float G = (float)r_g, S = (float)stride;
+            float o;
+            if (l15 < 2) { const float sg = sigmoidf_(g_raw) + (float)(l15 == 0 ? r_cell % r_g : r_cell / r_g); o = a.mode == 0 ? sg / G : sg * S; }
+            else {
+                float anc = a.h[0].anchors[0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (r_hd == k) anc = a.h[k].anchors[2 * r_an + (l15 - 2)];
+                const float e = expf(g_raw) * anc;                   // anchors pre-divided by stride on the host
+                o = a.mode == 0 ? e / G : e * S;
+            }
+            a.box4[(size_t)r_row * 4 + l15] = o;
+            if (l15 == 0) { scores[r_row] = rbest; labels[r_row] = rlabel; }
+        }
+    }
+    // (the list counter is zeroed by the NMS kernel that follows -- PostArgs::zero_word -- or by a memset in front of phase 1 when
+    //  no NMS ran since: a last-workgroup-done reset here cost a thousand more atomics on one word)
+}
+hipError_t launch_decode_lean(const LeanArgs &a, float *scores, int *labels, hipStream_t s)
+{
+    if (a.nheads < 1 || a.nheads > 4 || !a.box4 || !scores || !labels || 5 + a.classes > 128 || !a.list || !a.list_count) return hipErrorInvalidValue;
+    size_t blocks = ((size_t)a.total + 1023) / 1024; if (blocks > 256 * 2) blocks = 256 * 2;
+    hipLaunchKernelGGL(k_decode_yolo_lean_p1, dim3((unsigned)blocks), dim3(1024), 0, s, a, scores, labels);
+    hipLaunchKernelGGL(k_decode_yolo_lean_p2, dim3(1024), dim3(256), 0, s, a, scores, labels);
+    return hipGetLastError();
+}
+
 // ---- D2: V2 `decode` (V2/decode.py:13-47): sigmoid xy/obj, exp wh, softmax classes; stored as
 //      (bx, by, bw, bh, obj, cls...) normalised; corners are formed at selection time ----
 __global__ void k_decode_region(const DecodeArgs a)
@@ -460,12 +581,20 @@ __device__ __forceinline__ float iou_numpy_v3(float4 a, float4 b)
 #define NMS_THREADS 1024
 #define SORT_LDS 4096
 
+// LDS of k_nms_image, one pool for both paths (u64 units).  General path: sort keys [SORT_LDS] + alive bitset.  Fast path (at most
+// NMS_FAST candidates, the common case: a few hundred boxes pass a detection threshold): keys, the sorted candidates themselves and the
+// NMS_FAST x NMS_FAST suppression bit matrix.
+#define NMS_FAST 512
+#define NMS_POOL (NMS_FAST /*keys*/ + 2 * NMS_FAST /*boxes*/ + NMS_FAST / 2 * 3 /*label, score, row*/ + NMS_FAST * (NMS_FAST / 64) /*matrix*/)
+static_assert(NMS_POOL >= SORT_LDS + 512, "the general path's keys + alive bitset fit the pool");
+
 __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
 {
     float4 *sbox = a.sbox; int *slabel = a.slabel; float *sscore = a.sscore;
     const int img_h = a.img_h, img_w = a.img_w;
-    __shared__ unsigned long long skeys[SORT_LDS];
-    __shared__ unsigned int alive[1024];           // bitset for up to 32768 candidates
+    __shared__ unsigned long long pool[NMS_POOL];
+    unsigned long long *const skeys = pool;
+    unsigned int *const alive = (unsigned int *)(pool + SORT_LDS);      // bitset for up to 32768 candidates (general path)
     __shared__ int wave_cnt[NMS_THREADS / 64];
     __shared__ int s_base, s_cur, s_kept;
 
@@ -483,25 +612,140 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms_image(const PostArgs a)
     int *const rows_out = a.rows_out ? a.rows_out + (size_t)img * a.max_out : nullptr;
     int *const srow = a.rows_out ? a.srow + (size_t)img * a.rows : nullptr;      // row of every sorted candidate
     if (rows_out) for (int k = tid; k < a.max_out; k += NMS_THREADS) rows_out[k] = -1;
-    // (1) order-preserving compaction of rows whose score passes the threshold (tf.boolean_mask order)
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < a.rows; r0 += NMS_THREADS) {
-        int r = r0 + tid;
-        bool f = false;
-        if (r < a.rows) { float s = scores[r]; f = a.select_mode == 0 ? (s > a.score_thr) : (s >= a.score_thr); }
-        unsigned long long m = __ballot(f);
-        if (lane == 0) wave_cnt[wv] = __popcll(m);
-        __syncthreads();
-        int pre = 0, tot = 0;
-        for (int i = 0; i < NMS_THREADS / 64; ++i) { int c = wave_cnt[i]; if (i < wv) pre += c; tot += c; }
-        int base = s_base;
-        if (f) cand[base + pre + __popcll(m & ((1ull << lane) - 1))] = r;
-        __syncthreads();
-        if (tid == 0) s_base = base + tot;
-        __syncthreads();
+    if (a.zero_word && img == 0 && tid == 0) *a.zero_word = 0u;      // the lean decode's list counter, for the next step
+    // (1) order-preserving compaction of rows whose score passes the threshold (tf.boolean_mask order).  Every wave owns a contiguous run
+    // of rows and keeps the ballots of its 64-row steps in LDS: two barriers in all (one per 1024 rows made this phase a third of the
+    // kernel: a barrier of sixteen waves costs ~0.4 us)
+    const int per_wave = ((a.rows + NMS_THREADS - 1) / NMS_THREADS) * 64;          // rows per wave, a multiple of 64 (<= 2048)
+    const int steps = per_wave / 64;                                               // <= 32
+    unsigned long long *const wmask = pool + wv * 32;                              // this wave's ballots (the pool is free until the keys are built)
+    {
+        int cnt = 0;
+        const int r_lo = wv * per_wave;
+        // eight steps' loads in flight at a time (one load per step, each waited for by its ballot, was a chain of a dozen memory round trips)
+        for (int s0 = 0; s0 < steps; s0 += 8) {
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int r = r_lo + (s0 + u) * 64 + lane; sv[u] = (s0 + u < steps && r < a.rows) ? scores[r] : -INFINITY; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (s0 + u >= steps) break;
+                const int r = r_lo + (s0 + u) * 64 + lane;
+                const bool f = r < a.rows && (a.select_mode == 0 ? (sv[u] > a.score_thr) : (sv[u] >= a.score_thr));
+                const unsigned long long m = __ballot(f);
+                if (lane == 0) wmask[s0 + u] = m;
+                cnt += __popcll(m);
+            }
+        }
+        if (lane == 0) wave_cnt[wv] = cnt;
     }
+    __syncthreads();
+    {
+        int pre = 0, tot = 0;
+        for (int i = 0; i < NMS_THREADS / 64; ++i) { const int c = wave_cnt[i]; if (i < wv) pre += c; tot += c; }
+        const int r_lo = wv * per_wave;
+        for (int st = 0; st < steps; ++st) {
+            const unsigned long long m = wmask[st];
+            if ((m >> lane) & 1ull) cand[pre + __popcll(m & ((1ull << lane) - 1ull))] = r_lo + st * 64 + lane;
+            pre += __popcll(m);
+        }
+        if (tid == 0) s_base = tot;
+    }
+    __syncthreads();
     int M = s_base;
+    if (M <= NMS_FAST && a.nms_mode != 3) {
+        // ---- fast path: everything in LDS, five barriers (the general path pays two per kept box and ~40 for its sort).  Phase times at
+        //      ~150 candidates, 32 images (kernel trace, one MI355X): launch 4 us, compaction 2.5, keys + rank + gather 5, bit matrix 14, scan 5:
+        //      the matrix evaluates every later pair although a kept box is rare -- a lazily evaluated row per kept box is the next step.
+        //      Same keys, same gather arithmetic, same IoU functions and the same greedy
+        //      order as the general path below: identical records. ----
+        unsigned long long *const keys = pool;                                                  // [NMS_FAST]
+        float4 *const lbox = (float4 *)(pool + NMS_FAST);                                       // [NMS_FAST] sorted candidates
+        int *const llabel = (int *)(pool + 3 * NMS_FAST); float *const lscore = (float *)(llabel + NMS_FAST); int *const lrow = llabel + 2 * NMS_FAST;
+        unsigned long long *const mat = pool + 3 * NMS_FAST + NMS_FAST / 2 * 3;                 // [M][W] suppression bits
+        // (the barrier above also retired the ballots that shared the pool with the keys)
+        if (tid < M) {
+            unsigned int u = __float_as_uint(scores[cand[tid]]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone map of float order
+            keys[tid] = ((unsigned long long)(~u) << 32) | (unsigned int)tid;      // descending score, ascending candidate index
+        }
+        __syncthreads();
+        // rank sort: the keys are distinct, so a key's position is the number of smaller keys.  Eight lanes share a candidate (each
+        // counts an eighth of the keys; three shuffles add the parts up), two passes of the 1024 threads cover 256 candidates
+        for (int c0 = 0; c0 < M; c0 += NMS_THREADS / 8) {
+            const int ci = c0 + (tid >> 3), part = tid & 7;
+            const unsigned long long mykey = ci < M ? keys[ci] : 0ull;
+            int rank = 0;
+            for (int j = part; j < M; j += 8) rank += keys[j] < mykey ? 1 : 0;
+            rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2); rank += __shfl_xor(rank, 4);
+            if (ci < M && part == 0) {
+                const int row = cand[ci];
+                const float *p = a.box4 ? a.box4 + ((size_t)img * a.rows + row) * 4 : a.det + ((size_t)img * a.rows + row) * a.attrs;
+                float4 bx;
+                if (a.nms_mode == 2 || a.corners_in) bx = float4{p[0], p[1], p[2], p[3]};      // (cx,cy,w,h) for darknet; given corners
+                else if (a.nms_mode == 4) { float w2 = 0.5f * p[2], h2 = 0.5f * p[3]; bx = float4{p[0] - h2, p[1] - w2, p[0] + h2, p[1] + w2}; }      // YOLOv1's swapped extents, see below
+                else { float w2 = p[2] * 0.5f, h2 = p[3] * 0.5f; bx = float4{p[0] - w2, p[1] - h2, p[0] + w2, p[1] + h2}; }                          // V3/YOLOV3.py:348-351
+                if (a.nms_mode == 1 && img_w > 0) {            // V2/utils.py:32-43: scale to the image, truncate to int32, clip
+                    int x0 = (int)(bx.x * (float)img_w), y0 = (int)(bx.y * (float)img_h);
+                    int x1 = (int)(bx.z * (float)img_w), y1 = (int)(bx.w * (float)img_h);
+                    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, img_w - 1); y1 = min(y1, img_h - 1);
+                    bx = float4{(float)x0, (float)y0, (float)x1, (float)y1};
+                }
+                lbox[rank] = bx; llabel[rank] = labels[row]; lscore[rank] = scores[row]; lrow[rank] = row;
+            }
+        }
+        __syncthreads();
+        if (a.nms_mode == 1 && M > 400) M = 400;           // V2 numpy flavour keeps only the 400 best before NMS (bboxes_sort top_k, V2/utils.py:146-151)
+        // suppression bits: word (i, w) bit b set <=> candidate i, when kept, removes the later candidate j = 64 w + b.  One wave per
+        // word: lane b evaluates the pair (i, 64 w + b), the ballot IS the word
+        const int W = (M + 63) >> 6;
+        for (int e = wv; e < M * W; e += NMS_THREADS / 64) {
+            const int i = e / W, w = e - i * W;
+            unsigned long long bits = 0;
+            if (64 * w + 63 > i) {                           // (wave-uniform)
+                const int j = 64 * w + lane;
+                bool kill = false;
+                if (j > i && j < M) {
+                    const float4 bc = lbox[i], bj = lbox[j];
+                    if (a.nms_mode == 0 || a.nms_mode == 4) kill = iou_tf(bc, bj) > a.iou_thr;
+                    else if (a.nms_mode == 2) kill = llabel[j] == llabel[i] && iou_darknet(bc, bj) > a.iou_thr;
+                    else {
+                        const double v = iou_v2np(int4{(int)bc.x, (int)bc.y, (int)bc.z, (int)bc.w}, int4{(int)bj.x, (int)bj.y, (int)bj.z, (int)bj.w});
+                        kill = llabel[j] == llabel[i] && !(v < (double)a.iou_thr);
+                    }
+                }
+                bits = __ballot(kill);
+            }
+            if (lane == 0) mat[e] = bits;
+        }
+        __syncthreads();
+        // greedy scan by ONE wave: lane w holds word w of the alive set
+        if (wv == 0) {
+            unsigned long long al = 0;
+            if (lane < W) { const int lo = lane * 64; al = (M - lo >= 64) ? ~0ull : ((1ull << (M - lo)) - 1ull); }
+            int kept = 0;
+            const bool capped = a.nms_mode == 0 || a.nms_mode == 4;
+            for (int w = 0; w < W; ++w) {
+                while (true) {
+                    const unsigned long long cw = __shfl(al, w);          // (wave-uniform)
+                    if (!cw || (capped && kept >= a.max_out)) break;
+                    const int i = 64 * w + (int)__builtin_ctzll(cw);
+                    if (kept < a.max_out && lane == 0) {
+                        const float4 bc = lbox[i];
+                        out[kept] = BoxOut{bc.x, bc.y, bc.z, bc.w, lscore[i], llabel[i]};
+                        if (rows_out) rows_out[kept] = lrow[i];
+                    }
+                    ++kept;
+                    unsigned long long kill = lane < W ? mat[i * W + lane] : 0ull;
+                    if (lane == w) kill |= 1ull << (i & 63);
+                    al &= ~kill;
+                }
+                if (capped && kept >= a.max_out) break;
+            }
+            if (lane == 0) a.counts_out[img] = min(kept, a.max_out);
+        }
+        return;
+    }
     // V2 numpy flavour keeps only the 400 best before NMS (bboxes_sort top_k, V2/utils.py:146-151)
     int P = 1; while (P < M) P <<= 1;
     const bool in_lds = P <= SORT_LDS;

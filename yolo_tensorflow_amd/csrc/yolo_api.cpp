@@ -41,6 +41,7 @@ struct Layer {
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
+    float *d_obj = nullptr;              // ... feeding a [yolo] layer (bf16 / fp8 networks): compact plane of its objectness logits [max_batch * H * W][anchors]
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one
@@ -87,7 +88,9 @@ struct yolo_ctx {
     float in_mul = 1.f, in_add = 0.f;     // input normalisation after the /255: v * in_mul + in_add ([net] yolo_input_mul / yolo_input_add)
     float *d_det = nullptr; int rows = 0, attrs = 0;
     // lean detect path (yolo_detect*): the decode writes scores, labels and the four box numbers of every row, not the tensor
-    float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false; float lean_thr = 0.f;
+    bool lean_cnt_dirty = false;
+    void *d_lean_list = nullptr; unsigned *d_lean_cnt = nullptr;      // lean decode: list of the boxes that pass the objectness pre-filter + its counters
+    float *d_box4 = nullptr; bool lean = false, det_valid = false, lean_ok = false; float lean_thr = 0.f; int lean_heads = 0;      // lean_heads: [yolo] heads when all can share one decode launch, else 0
     // postprocess workspace
     float *d_scores = nullptr; int *d_labels = nullptr; int *d_cand = nullptr; unsigned long long *d_keys = nullptr;
     float4 *d_sbox = nullptr; int *d_slabel = nullptr; float *d_sscore = nullptr; int rows_pow2 = 0;
@@ -463,10 +466,17 @@ int allocate(yolo_ctx *c)
     size_t nr = (size_t)c->max_batch * c->rows;
     HIPCK(c, hipMalloc((void **)&c->d_det, nr * c->attrs * 4));
     HIPCK(c, hipMalloc((void **)&c->d_box4, nr * 16));
+    HIPCK(c, hipMalloc(&c->d_lean_list, nr * 16)); HIPCK(c, hipMalloc((void **)&c->d_lean_cnt, 16)); HIPCK(c, hipMemsetAsync(c->d_lean_cnt, 0, 16, c->stream));
     c->lean_ok = true;                  // every head a [yolo] head the cell-per-wave decode serves
     for (auto &L : c->layers) {
         if (L.type == L_REGION || L.type == L_DETECT) c->lean_ok = false;
         if (L.type == L_YOLO && L.na * (5 + L.classes) > 256) c->lean_ok = false;
+    }
+    c->lean_heads = 0;
+    if (c->lean_ok) {
+        int classes = -1; bool same = true;
+        for (auto &L : c->layers) if (L.type == L_YOLO) { ++c->lean_heads; same = same && (classes < 0 || classes == L.classes) && L.na <= 16 && 5 + L.classes <= 128; classes = L.classes; }
+        if (!same || (size_t)c->max_batch * c->rows * 340 >= 0xffffffffull) c->lean_heads = 0;      // 32-bit element offsets in the kernel
     }
     c->rows_pow2 = 1; while (c->rows_pow2 < c->rows) c->rows_pow2 <<= 1;
     HIPCK(c, hipMalloc((void **)&c->d_scores, nr * 4)); HIPCK(c, hipMalloc((void **)&c->d_labels, nr * 4));
@@ -480,6 +490,11 @@ int allocate(yolo_ctx *c)
         HIPCK(c, hipMalloc((void **)&L.d_b, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_b, 0, (size_t)L.cout_pad * 4, c->stream));
         if (L.in_dt == DT_FP8) { HIPCK(c, hipMalloc((void **)&L.d_sc, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_sc, 0, (size_t)L.cout_pad * 4, c->stream)); }
     }
+    if (c->dtype != YOLO_FP32)
+        for (size_t i = 1; i < c->layers.size(); ++i) {
+            const Layer &Y = c->layers[i]; Layer &P = c->layers[i - 1];
+            if (Y.type == L_YOLO && P.type == L_CONV && P.head && !P.fc) HIPCK(c, hipMalloc((void **)&P.d_obj, (size_t)c->max_batch * P.H * P.W * Y.na * 4));
+        }
     HIPCK(c, hipStreamSynchronize(c->stream));
     return YOLO_OK;
 }
@@ -508,6 +523,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     }
     a.N = n; a.H = in.h; a.W = in.w; a.Cin_pad = L.cin_pad; a.Ho = L.H; a.Wo = L.W; a.Cout = L.filters;
     a.ksize = L.size; a.stride = L.stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, L.in_dt); a.act = L.act; a.zeros = c->d_zeros;
+    if (L.d_obj && li + 1 < (int)c->layers.size()) { const Layer &Y = c->layers[li + 1]; a.obj_out = L.d_obj; a.obj_attrs = 5 + Y.classes; a.obj_na = Y.na; conv_magic((uint32_t)a.obj_attrs, a.obj_mul, a.obj_shift); }
     if (L.fc) { a.H = a.W = 1; a.in_stride = L.fc_h * L.fc_w * in.stride; }         // one "pixel" per image: the flattened producer
     if (L.s2d7) { a.in = c->s2d.ptr; a.in_stride = 32; a.H = c->s2d.h; a.W = c->s2d.w; a.ksize = 4; a.stride = 1; a.pad = 2; }   // see pack_s2d7
     conv_finalize(a);
@@ -585,6 +601,32 @@ int run_layer(yolo_ctx *c, int i, int n)
                                   c->d_scores, c->d_labels, s));
         break; }
     case L_YOLO: case L_REGION: {
+        if (c->lean && c->lean_thr > 0.f && c->lean_heads >= 1 && c->lean_heads <= 4 && !getenv("YOLO_NO_LEAN_MULTI")) {
+            // lean detect path: every [yolo] head is decoded by ONE launch, issued at the last head (the head tensors keep their own buffers)
+            bool later_head = false;
+            for (size_t k = i + 1; k < c->layers.size(); ++k) later_head |= c->layers[k].type == L_YOLO;
+            if (later_head) break;
+            LeanArgs la; memset(&la, 0, sizeof la);
+            long begin = 0;
+            for (size_t k = 0; k < c->layers.size(); ++k) {
+                const Layer &Y = c->layers[k];
+                if (Y.type != L_YOLO) continue;
+                const Layer &P = c->layers[k - 1];
+                LeanHead &h = la.h[la.nheads++];
+                h.raw = (const float *)P.out.ptr; h.obj = P.d_obj; h.raw_stride = P.out.stride; h.g = Y.H; h.na = Y.na; h.row_off = Y.row_off; h.box_begin = begin;
+                const int stride = c->in_h / Y.H;
+                for (int q = 0; q < 2 * Y.na; ++q) h.anchors[q] = (float)(1.0 * (double)Y.anchors[q] / (double)stride);
+                begin += (long)n * Y.H * Y.W * Y.na;
+            }
+            la.total = begin; la.n = n; la.classes = L.classes; la.img_size = c->in_h; la.mode = c->decode; la.rows_total = c->rows;
+            la.box4 = c->d_box4; la.reject_below = c->lean_thr; la.list = (uint4 *)c->d_lean_list; la.list_count = c->d_lean_cnt; la.list_cap = (unsigned)((size_t)c->max_batch * c->rows);
+            // the list counter must be zero: the NMS launch of the previous detect call resets it; if none ran since the last decode
+            // (a failed call in between), a memset does
+            if (c->lean_cnt_dirty) HIPCK(c, hipMemsetAsync(c->d_lean_cnt, 0, 16, s));
+            c->lean_cnt_dirty = true;
+            HIPCK(c, launch_decode_lean(la, c->d_scores, c->d_labels, s));
+            break;
+        }
         DecodeArgs d; memset(&d, 0, sizeof d);
         const Layer &P = c->layers[i - 1];
         d.raw = (const float *)P.out.ptr; d.raw_stride = P.out.stride; d.n = n; d.g = L.H; d.na = L.na; d.classes = L.classes;
@@ -656,7 +698,9 @@ int post(yolo_ctx *c, const float *det, int n, int rows, int attrs, float score_
     if (direct_b) p.boxes_out = boxes_out;
     if (direct_c) p.counts_out = (int *)counts_out;
     if (rows_out) { p.srow = c->d_srow; p.rows_out = out_loc != YOLO_HOST ? (int *)rows_out : c->d_rows; }
+    if (c->lean_cnt_dirty) p.zero_word = c->d_lean_cnt;
     HIPCK(c, launch_postprocess(p, c->stream));
+    c->lean_cnt_dirty = false;
     if (rows_out && out_loc == YOLO_HOST) { int r = copy_out(c, rows_out, c->d_rows, need * 4, out_loc); if (r) return r; }
     if (boxes_out && !direct_b) { int r = copy_out(c, boxes_out, c->d_boxes, need * sizeof(yolo_box), out_loc); if (r) return r; }
     if (counts_out && !direct_c) { int r = copy_out(c, counts_out, c->d_counts, (size_t)n * 4, out_loc); if (r) return r; }
@@ -786,9 +830,9 @@ void yolo_destroy(yolo_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void *p : c->phys) if (p) hipFree(p);
-    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); if (L.d_wf) hipFree(L.d_wf); }
+    for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); if (L.d_wf) hipFree(L.d_wf); if (L.d_obj) hipFree(L.d_obj); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
-                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr, c->d_srow, c->d_rows};
+                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr, c->d_srow, c->d_rows, c->d_lean_list, c->d_lean_cnt};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
