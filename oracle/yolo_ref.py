@@ -716,7 +716,56 @@ def dn_nms_sort(boxes_cxcywh, probs, thresh):
 # ----------------------------------------------------------------------------------------------
 # whole network (rows B, Y, Net): cfg-driven forward
 # ----------------------------------------------------------------------------------------------
-def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, collect=None):
+def flatten_weights(params, secs):
+    """Inverse of unflatten_weights: the per-conv dicts back into darknet's flat stream (file order, filters OIHW)."""
+    parts = []
+    for c, p in zip(conv_layers(secs), params):
+        if c["bn"]:
+            parts += [p["beta"], p["gamma"], p["mean"], p["var"]]
+        else:
+            parts.append(p["bias"])
+        parts.append(np.transpose(p["w_hwio"], (3, 2, 0, 1)).reshape(-1))            # HWIO -> OIHW
+    return np.concatenate([np.asarray(q, dtype=np.float32).reshape(-1) for q in parts])
+
+
+def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35, 1.5)):
+    """Make a synthetic parameter set behave like a TRAINED file on the given images: one forward pass in which every batch-normalised
+    conv's filters are rescaled per output channel to a target variance drawn from the ranges of the reference's dump of real files
+    (D2T/log.txt: 2e-3 .. 0.3 on the first two layers, 0.6 .. 19 after, a few per cent down to 8e-4) and its rolling mean / variance
+    are set to what those filters produce on `images01` ([N,S,S,3] in 0..1) -- training's running averages.  gamma / beta are left as
+    drawn (darknet_io.synth_weights(stats="log"): gamma to 4.7, some negative, beta to -11).  Head convs are rescaled so that their raw
+    outputs have standard deviation `head_std` = (centre logits, log-size offsets, objectness / class logits) around their biases -- a
+    trained detector's size offsets stay within about +-1 (boxes 0.3 .. 3 anchors), not the +-5 of an unscaled random filter.  Without this the analytic statistics of the generator hold for
+    white-noise inputs only: on natural images neighbouring taps add coherently and the activations grow layer by layer.
+    Test infrastructure (no reference counterpart: the reference ships no weights).  Returns the calibrated params (modified in place)."""
+    rng = np.random.default_rng(seed)
+
+    def hook(i, p, y):
+        n = y.shape[-1]
+        m = y.mean((0, 1, 2), dtype=np.float64); v = y.var((0, 1, 2), dtype=np.float64)
+        if "bias" in p:
+            attrs = None
+            for h in secs[1:][i + 1:i + 2]:
+                if h["type"] in ("yolo", "region"):
+                    attrs = 5 + int(h.get("classes", 20))
+            k = np.arange(n) % attrs if attrs and n % attrs == 0 else np.full(n, 4)
+            want = np.where(k < 2, head_std[0], np.where(k < 4, head_std[1], head_std[2]))
+            sc = want / np.sqrt(np.maximum(v, 1e-20))
+        else:
+            lo, hi = (2e-3, 0.3) if i < 2 else (0.6, 19.0)
+            target = np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+            tiny = rng.random(n) < 0.03
+            target[tiny] = np.exp(rng.uniform(np.log(8e-4), np.log(1e-2), int(tiny.sum())))
+            sc = np.sqrt(target / np.maximum(v, 1e-20))
+            p["mean"] = (m * sc).astype(np.float32); p["var"] = (target * rng.uniform(0.9, 1.1, n)).astype(np.float32)
+        p["w_hwio"] = (p["w_hwio"] * sc[None, None, None, :]).astype(np.float32)
+        return (y * sc.astype(np.float32)).astype(np.float32)
+
+    forward(secs, params, images01, calibrate=hook)
+    return params
+
+
+def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, collect=None, calibrate=None):
     """Run the cfg (yolov3 == V3/yolo_v3.py:195-267; yolov2 == V2/model_darknet19_slim.py:119-200; ...)
     on x [N,S,S,3] float32 **already scaled to 0..1** (the /255 of V3/yolo_v3.py:215 is applied by the
     caller, as D2T `_input_process` does).
@@ -764,6 +813,9 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
             if emulate_bf16:
                 w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
                 y = conv2d_nhwc(x, to_bf16(w), st) + b
+            elif calibrate is not None:          # (calibrate_bn_statistics: the hook sees the raw conv output and rewrites p)
+                y = calibrate(i, p, conv2d_nhwc(x, p["w_hwio"], st))
+                y = y + p["bias"] if "bias" in p else batch_norm(y, p, bn_mode)
             elif "bias" in p:
                 y = conv2d_nhwc(x, p["w_hwio"], st) + p["bias"]
             else:

@@ -129,8 +129,9 @@ def write_weights_file(path, flat, major=0, minor=2, revision=0, seen=0):
         np.asarray(flat, dtype=np.float32).tofile(f)
 
 
-def synth_weights(secs, seed=0, obj_bias=-0.75):
+def synth_weights(secs, seed=0, obj_bias=-0.75, stats="benign"):
     """Seeded synthetic parameter stream, valid for any supported topology.
+    stats="log": batch-norm statistics in the ranges of the reference's dump of real files (see synth_weights_log).
 
     Filters W ~ N(0, 2/(k*k*Cin)) (darknet's own init, DN/convolutional_layer.c:205-209); gamma ~ U(.8,1.2),
     beta ~ N(0,.1), rolling_mean ~ N(0,.1).  rolling_variance is set to the *expected* variance of the
@@ -138,6 +139,8 @@ def synth_weights(secs, seed=0, obj_bias=-0.75):
     network's statistics look like -- so activations stay O(1) through 75 layers instead of growing
     ~1.1x per layer (the reference's real files span var 2e-3..16, D2T/log.txt).  Head convs: small
     filters, class/box biases N(0,1)/N(0,.5), objectness bias `obj_bias` (a few % of candidates pass 0.5)."""
+    if stats == "log":
+        return synth_weights_log(secs, seed, obj_bias)
     rng = np.random.default_rng(seed)
     layers = secs[1:]
     shapes = layer_shapes(secs)
@@ -196,6 +199,105 @@ def synth_weights(secs, seed=0, obj_bias=-0.75):
             cur = sum(m2[l] * shapes[l][3] for l in ls) / tot
         m2.append(cur)
     return np.concatenate(parts).astype(np.float32)
+
+
+def _leaky_moments(mean, std, slope):
+    """(E[f(y)], E[f(y)^2]) for y ~ N(mean, std^2) and f = leaky ReLU with `slope` (slope 1: identity); arrays per channel."""
+    from math import pi
+    std = np.maximum(std, 1e-12)
+    z = mean / std
+    cdf = 0.5 * (1.0 + _erf(z / np.sqrt(2.0))); pdf = np.exp(-0.5 * z * z) / np.sqrt(2.0 * pi)
+    m_pos = mean * cdf + std * pdf                                   # E[y 1(y > 0)]
+    s_pos = (mean * mean + std * std) * cdf + mean * std * pdf       # E[y^2 1(y > 0)]
+    m1 = m_pos + slope * (mean - m_pos)
+    m2 = s_pos + slope * slope * (mean * mean + std * std - s_pos)
+    return m1, m2
+
+
+def _erf(x):
+    # Abramowitz-Stegun 7.1.26, |err| < 1.5e-7: plenty for the moment bookkeeping (numpy has no erf)
+    sign = np.sign(x); x = np.abs(x)
+    t = 1.0 / (1.0 + 0.3275911 * x)
+    y = 1.0 - (((((1.061405429 * t - 1.453152027) * t) + 1.421413741) * t - 0.284496736) * t + 0.254829592) * t * np.exp(-x * x)
+    return sign * y
+
+
+def synth_weights_log(secs, seed=0, obj_bias=-0.75):
+    """Seeded synthetic parameters with the batch-norm statistics of a TRAINED darknet file -- the ranges the reference's own dump of
+    yolov3.weights / yolov2.weights documents (D2T/log.txt:1-949): gamma 0.0017 .. 4.7 and a few per cent of them negative, beta out to
+    -11, rolling means out to +-11, rolling variances from 8e-4 (first layers) to 19 -- instead of the benign gamma ~ U(.8, 1.2),
+    var ~ 1 of `synth_weights`.  The network must still behave like a trained one (activations O(1) through 75 layers), so the rolling
+    statistics are not drawn freely: filters are scaled per output channel to hit a log-uniform target variance, and rolling mean /
+    variance are then what those filters PRODUCE on inputs with the per-channel mean / variance tracked analytically through conv,
+    BN, leaky ReLU, shortcut, route, upsample and pooling (independence between channels and taps assumed) -- what training's running
+    averages would have recorded, within ten or twenty per cent."""
+    rng = np.random.default_rng(seed)
+    layers = secs[1:]
+    shapes = layer_shapes(secs)
+    cin0 = int(secs[0].get("channels", 3))
+    mean = [None] * len(layers); var = [None] * len(layers)            # per-channel first / second central moment of every layer's output
+    m_in, v_in = np.full(cin0, 0.5), np.full(cin0, 1.0 / 12.0)         # uniform [0, 1) pixels
+    parts = []
+    for i, s in enumerate(layers):
+        t = s["type"]
+        pm, pv = (mean[i - 1], var[i - 1]) if i else (m_in, v_in)
+        if t == "convolutional":
+            n, k, cin = int(s["filters"]), int(s["size"]), shapes[i][4]
+            head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
+            w = rng.normal(0, 1.0, (n, cin, k * k))
+            ex2 = pv + pm * pm
+            if int(s.get("batch_normalize", 0)):
+                # target rolling variance: first two convs (pixel inputs, small filters) 2e-3 .. 0.3, later layers 0.6 .. 19, 3 % tiny
+                lo, hi = (2e-3, 0.3) if i < 2 else (0.6, 19.0)
+                target = np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+                tiny = rng.random(n) < 0.03
+                target[tiny] = np.exp(rng.uniform(np.log(8e-4), np.log(1e-2), int(tiny.sum())))
+                unit_var = (w * w * pv[None, :, None]).sum((1, 2))
+                w *= np.sqrt(target / np.maximum(unit_var, 1e-30))[:, None, None]
+                rmean = (w * pm[None, :, None]).sum((1, 2))                                  # what the conv produces on average
+                rvar = target * rng.uniform(0.9, 1.1, n)                                     # running average vs this batch
+                gamma = np.exp(rng.normal(0.25, 0.45, n)); gamma = np.clip(gamma, 0.0017, 4.7)
+                gamma *= np.where(rng.random(n) < 0.06, -1.0, 1.0)
+                beta = np.where(rng.random(n) < 0.12, rng.normal(0, 4.0, n), rng.normal(0, 1.0, n)).clip(-11.2, 4.5)
+                parts += [beta, gamma, rmean, rvar, w.reshape(-1)]
+                std = np.abs(gamma) * np.sqrt(target / (rvar + 1e-5))
+                m1, m2 = _leaky_moments(beta, std, 0.1 if s.get("activation", "linear") == "leaky" else 1.0)
+            else:
+                b = rng.normal(0, 1.0, n)
+                if head:
+                    h = layers[i + 1]
+                    classes = int(h.get("classes", 20))
+                    na = len(h["mask"].split(",")) if "mask" in h else int(h.get("num", 1))
+                    attrs = 5 + classes
+                    if na * attrs == n:
+                        b = b.reshape(na, attrs)
+                        b[:, 0:4] = rng.normal(0, .5, (na, 4))
+                        b[:, 4] = obj_bias + rng.normal(0, .5, na)
+                        b = b.reshape(-1)
+                w *= np.sqrt(1.0 / np.maximum((ex2[None, :, None] * np.ones((1, 1, k * k))).sum(), 1e-30))
+                parts += [b, w.reshape(-1)]
+                m1, m2 = b + (w * pm[None, :, None]).sum((1, 2)), None
+                v_out = (w * w * pv[None, :, None]).sum((1, 2))
+                m2 = v_out + m1 * m1
+            mean[i] = m1; var[i] = np.maximum(m2 - m1 * m1, 1e-12)
+        elif t == "shortcut":
+            f = int(s["from"]); f = f if f >= 0 else i + f
+            mean[i] = mean[i - 1] + mean[f]; var[i] = var[i - 1] + var[f]
+        elif t == "route":
+            ls = [int(x) for x in s["layers"].split(",")]
+            ls = [l if l >= 0 else i + l for l in ls]
+            mean[i] = np.concatenate([mean[l] for l in ls]); var[i] = np.concatenate([var[l] for l in ls])
+        elif t == "reorg":
+            st = int(s.get("stride", 1)); mean[i] = np.tile(pm, st * st); var[i] = np.tile(pv, st * st)
+        elif t == "maxpool":
+            mean[i] = pm + 0.8 * np.sqrt(pv); var[i] = 0.6 * pv            # rough: max of a few correlated samples
+        elif t in ("upsample", "dropout"):
+            mean[i] = pm; var[i] = pv
+        elif t in ("yolo", "region", "detection"):
+            mean[i] = pm; var[i] = pv
+        else:
+            raise ValueError("synth_weights_log: unsupported layer type [%s]" % t)
+    return np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for q in parts]).astype(np.float32)
 
 
 def default_header(secs):
