@@ -68,9 +68,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
-    ap.add_argument("--dtype", choices=("bf16", "fp8", "fp32"), default="bf16",
+    ap.add_argument("--dtype", choices=("bf16", "fp8", "fp32", "fp16"), default="bf16",
                     help="bf16 is BASELINE.json's headline configuration; fp8 is its config 5; fp32 is the exact-fp32 MFMA path, the one "
-                         "that meets north_star's IoU >= 0.999 (each reported as a separate line)")
+                         "that meets north_star's IoU >= 0.999; fp16 is the bf16 configuration with IEEE fp16 storage (same kernels, plans and "
+                         "MFMA rate, 11-bit significand) (each reported as a separate line)")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +97,8 @@ def main():
     fp8 = args.dtype == "fp8"
     fp32 = args.dtype == "fp32"
     peak = PEAK_FP8_TFLOPS if fp8 else PEAK_F32_TFLOPS if fp32 else PEAK_BF16_TFLOPS
-    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.FP32 if fp32 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
+    fp16 = args.dtype == "fp16"
+    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.FP32 if fp32 else hip.FP16 if fp16 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
                      device=local_rank, stream=stream.cuda_stream)
     eng.set_weights(flat)
     # this rank's shard of the global batch (weak scaling: B images per GPU), resident in HBM
@@ -111,7 +113,8 @@ def main():
     gather = ydist.PipelinedGather(rec) if (world > 1 or force_dist) else None
     eng.forward(images, want_detections=False)
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
-    tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, args.dtype))
+    # (fp16 runs the bf16 configuration's kernels shape for shape: it shares that plan)
+    tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, "bf16" if fp16 else args.dtype))
     loaded = False
     if os.path.exists(tuned) and not args.retune:
         try:
@@ -184,7 +187,7 @@ def main():
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "YOLOv3 %dx%d batch=%d per GPU, %s: conv stack + head decode + threshold + TF-NMS%s"
-                                   % (args.size, args.size, B, "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "exact fp32 (f32 MFMA)" if fp32 else "bf16",
+                                   % (args.size, args.size, B, "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "exact fp32 (f32 MFMA)" if fp32 else "fp16 storage, fp32 accumulation" if fp16 else "bf16",
                                       " + RCCL all-gather of box records" if G > 1 else ""),
                        "global_batch": B * G, "input": "uint8 NHWC resident in HBM", "weights": "seeded synthetic darknet stream (seed 0)",
                        "parallelism": "dp%d" % G if G == 1 else

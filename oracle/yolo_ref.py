@@ -44,6 +44,11 @@ def to_bf16(x):
     return np.where(np.isnan(x), x, out)
 
 
+def to_f16(x):
+    """Round float32 -> IEEE fp16 (RNE, saturating at +-65504 as the device's conversions do) -> float32: the YOLO_FP16 storage type."""
+    return np.clip(np.asarray(x, np.float32), -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+
+
 def to_fp8_e4m3(x):
     """Round float32 -> OCP e4m3 (e4m3fn: 4 exponent bits, bias 7, 3 mantissa bits, no infinities, max 448),
     round-to-nearest-even, saturating at +-448, returned as float32 values on the e4m3 grid.  Emulates the
@@ -765,7 +770,7 @@ def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35,
     return params
 
 
-def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, collect=None, calibrate=None):
+def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, collect=None, calibrate=None, storage=None):
     """Run the cfg (yolov3 == V3/yolo_v3.py:195-267; yolov2 == V2/model_darknet19_slim.py:119-200; ...)
     on x [N,S,S,3] float32 **already scaled to 0..1** (the /255 of V3/yolo_v3.py:215 is applied by the
     caller, as D2T `_input_process` does).
@@ -777,7 +782,10 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
                           device's storage precision; head conv outputs stay fp32 (device keeps them fp32).
     Returns (heads, outs): heads = list of (section, raw head tensor [N,g,g,ch] fp32) in cfg order;
     outs = list of per-layer NHWC outputs (None for yolo/region) when collect is not None."""
-    q = to_bf16 if emulate_bf16 else (lambda a: a)
+    # storage: "bf16" (== emulate_bf16=True) or "f16": the device's 16-bit storage types (folded filters and stored activations rounded)
+    if storage is not None:
+        emulate_bf16 = True
+    q = (to_f16 if storage == "f16" else to_bf16) if emulate_bf16 else (lambda a: a)
     x = q(np.asarray(x, dtype=np.float32))
     layers = secs[1:]
     outs = []
@@ -792,7 +800,7 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
             is_head = i + 1 < len(layers) and layers[i + 1]["type"] == "detection"
             w = p["w_hwio"].reshape(-1, p["w_hwio"].shape[-1])            # [inputs (CHW order), output]
             flat = np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2))).reshape(x.shape[0], -1)
-            y = (flat @ (to_bf16(w) if emulate_bf16 else w) + p["bias"]).astype(np.float32)
+            y = (flat @ (q(w) if emulate_bf16 else w) + p["bias"]).astype(np.float32)
             act = s.get("activation", "logistic")
             if act == "leaky":
                 y = leaky_relu(y)
@@ -812,7 +820,7 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
             is_head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
             if emulate_bf16:
                 w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
-                y = conv2d_nhwc(x, to_bf16(w), st) + b
+                y = conv2d_nhwc(x, q(w), st) + b
             elif calibrate is not None:          # (calibrate_bn_statistics: the hook sees the raw conv output and rewrites p)
                 y = calibrate(i, p, conv2d_nhwc(x, p["w_hwio"], st))
                 y = y + p["bias"] if "bias" in p else batch_norm(y, p, bn_mode)

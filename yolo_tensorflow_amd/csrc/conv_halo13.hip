@@ -6,7 +6,7 @@
 bool conv_halo13_ok(const ConvArgs &a)
 {
     const int row = a.in_dt == DT_FP8 ? 128 : 64;                  // channels of one 128-byte chunk
-    if (a.in_dt != DT_BF16 && a.in_dt != DT_FP8) return false;
+    if (a.in_dt != DT_BF16 && a.in_dt != DT_FP8 && a.in_dt != DT_F16) return false;
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.H % HALO_B || a.W % HALO_B || a.Cin_pad % row || a.kchunk != row || a.Kpad != 9 * a.Cin_pad) return false;
     if (a.out_dt == DT_F32) return false;
@@ -14,7 +14,7 @@ bool conv_halo13_ok(const ConvArgs &a)
     return (double)a.N * a.H * a.W * a.in_stride * dt_size(a.in_dt) < 2147483648.0;
 }
 
-template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2>
+template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2, bool H16 = false>
 static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
 {
     constexpr int WP = 1, TP = 11, BK = 64, BC = WC * TC * 16;
@@ -22,9 +22,9 @@ static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
     const long tiles = blocks * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL, true>();
     static_assert(lds <= 160 * 1024, "halo form: LDS");
-    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>, lds);
+    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, HALO_B));
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, HALO_B));
     return hipGetLastError();
 }
 
@@ -52,6 +52,20 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
 {
     if (!conv_halo13_ok(a)) return hipErrorInvalidValue;
     const bool f8 = a.in_dt == DT_FP8;
+    if (a.in_dt == DT_F16) {
+        if (a.out_dt != DT_F16) return hipErrorInvalidValue;
+        switch (cfg) {
+        case 36: return launch_h<8, 2, 0, 2, false, 2, true>(a, s);
+        case 37: return launch_h<8, 2, 4, 2, false, 2, true>(a, s);
+        case 38: return launch_h<4, 2, 4, 2, false, 2, true>(a, s);
+        case 39: return launch_h<4, 2, 0, 2, false, 2, true>(a, s);
+        case 40: return launch_h<8, 2, 0, 2, true, 2, true>(a, s);
+        case 41: return launch_h<8, 1, 0, 2, true, 2, true>(a, s);
+        case 42: return launch_h<4, 2, 0, 2, true, 2, true>(a, s);
+        case 43: return launch_h<8, 1, 0, 2, true, 3, true>(a, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (cfg) {
     case 36: return f8 ? launch_h<8, 2, 0, 1>(a, s) : launch_h<8, 2, 0, 2>(a, s);
     case 37: return f8 ? launch_h<8, 2, 4, 1>(a, s) : launch_h<8, 2, 4, 2>(a, s);

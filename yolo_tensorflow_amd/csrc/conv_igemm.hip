@@ -64,7 +64,7 @@ hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s) { return a.in_dt =
 // 9 taps x 8 channels = 72 (padded to 96).  No LDS: a lane's MFMA B fragment for K-group (kk, lq) is exactly the
 // 16-byte channel vector of ONE input pixel (tap kk*4+lq), so it is a single global_load_dwordx4; the filters
 // (Cout x 96 bf16) live in registers for the whole wave.  One wave computes 16 pixels x Cout per step.
-template <int TC>
+template <int TC, bool H16 = false>
 __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
             for (int i = 0; i < TC; ++i) {
                 acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 3; ++kk) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][kk], fx[u][kk], acc[i], 0, 0, 0);
+                for (int kk = 0; kk < 3; ++kk) acc[i] = mma16<H16>(fw[i][kk], fx[u][kk], acc[i]);
             }
             if (mrow[u] >= 0) {
 #pragma unroll
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.1f * v[q]);     // == v > 0 ? v : 0.1 v
                     uint2 pk;
-                    pk.x = f32_to_bf16_rn(v[0]) | (f32_to_bf16_rn(v[1]) << 16);
-                    pk.y = f32_to_bf16_rn(v[2]) | (f32_to_bf16_rn(v[3]) << 16);
-                    if (a.out_dt == DT_FP8) {
+                    pk.x = pack16x2<H16>(v[0], v[1]);
+                    pk.y = pack16x2<H16>(v[2], v[3]);
+                    if (!H16 && a.out_dt == DT_FP8) {
                         // same value chain as the tiled kernel: bf16 rounding, then e4m3 of value / scale_out
                         const float s8 = a.out_inv_scale;
                         const uint32_t w8 = f32x2_to_fp8<true>(bf16_bits_to_f32(pk.y & 0xffff) * s8, bf16_bits_to_f32(pk.y >> 16) * s8,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
 
 bool conv_c8_direct_ok(const ConvArgs &a)
 {
-    return a.in_dt == DT_BF16 && a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin_pad == 8 && a.out_dt != DT_F32 && !a.res && a.Kpad >= 96 &&
+    return (a.in_dt == DT_BF16 || (a.in_dt == DT_F16 && a.out_dt == DT_F16)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin_pad == 8 && a.out_dt != DT_F32 && !a.res && a.Kpad >= 96 &&
            (a.Cout == 16 || a.Cout == 32 || a.Cout == 64);
 }
 
@@ -157,7 +157,12 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
     long waves = (M + 63) / 64;
     long blocks = (waves + 3) / 4; if (blocks > 256 * 8) blocks = 256 * 8;
     dim3 grid((unsigned)blocks), block(256);
-    if (a.Cout == 16) hipLaunchKernelGGL((conv_c8_3x3_direct<1>), grid, block, 0, s, a);
+    if (a.in_dt == DT_F16) {
+        if (a.Cout == 16) hipLaunchKernelGGL((conv_c8_3x3_direct<1, true>), grid, block, 0, s, a);
+        else if (a.Cout == 32) hipLaunchKernelGGL((conv_c8_3x3_direct<2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_c8_3x3_direct<4, true>), grid, block, 0, s, a);
+    }
+    else if (a.Cout == 16) hipLaunchKernelGGL((conv_c8_3x3_direct<1>), grid, block, 0, s, a);
     else if (a.Cout == 32) hipLaunchKernelGGL((conv_c8_3x3_direct<2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_c8_3x3_direct<4>), grid, block, 0, s, a);
     return hipGetLastError();
@@ -224,7 +229,7 @@ int conv_pick_cfg(const ConvArgs &a)
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI, int EB>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI, int EB, bool H16 = false>
 static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
@@ -233,27 +238,36 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL>();
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * (WP * WC + NL));   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
-        hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>, lds);
+        hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16>, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB>), grid, block, lds, s, conv_tile_magic(a, BC, 0));
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16>), grid, block, lds, s, conv_tile_magic(a, BC, 0));
     return hipGetLastError();
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, int EB>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, int EB, bool H16 = false>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets: the activation window must stay below 2 GiB
     if (((double)a.N * a.H * a.W * a.in_stride + 2.0 * (a.W + 1) * a.in_stride) * EB >= 2147483648.0) return hipErrorInvalidValue;
     constexpr int BKE = BK * 2 / EB;
     if (a.Kpad % BKE) return hipErrorInvalidValue;
-    return (a.Cin_pad % BKE) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true, EB>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false, EB>(a, s);
+    return (a.Cin_pad % BKE) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true, EB, H16>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false, EB, H16>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
 {
-    if (a.in_dt != DT_BF16) return hipErrorInvalidValue;
+    // (16-bit storage: bf16, or fp16 -- the same tile table, the same kernels with the other MFMA and conversions)
+    if (a.in_dt != DT_BF16 && a.in_dt != DT_F16) return hipErrorInvalidValue;
+    if (a.in_dt == DT_F16 && a.out_dt != DT_F16 && a.out_dt != DT_F32) return hipErrorInvalidValue;
     if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
+    if (a.in_dt == DT_F16)
+        switch (cfg) {
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2, true>(a, s);
+            CONV_CFGS(X)
+#undef X
+        default: break;
+        }
     switch (cfg) {
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2>(a, s);
         CONV_CFGS(X)

@@ -24,6 +24,31 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi)
 {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
+// ---- 16-bit storage type of the EB = 2 kernels: bf16 (8-bit significand) or, H16 = true, IEEE fp16 (11-bit significand; same MFMA
+//      rate, v_mfma_f32_16x16x32_f16).  Values beyond fp16's range saturate at +-65504 on the way to memory. ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#define F16_MAX 65504.0f
+template <bool H16> __device__ __forceinline__ uint32_t pack16x2(float lo, float hi)
+{
+    if constexpr (H16) {
+        lo = __builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX); hi = __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX);
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));       // RNE
+    } else return f32x2_to_bf16x2(lo, hi);
+}
+template <bool H16> __device__ __forceinline__ float unpack16_lo(uint32_t w)
+{
+    if constexpr (H16) return (float)__builtin_bit_cast(f16x2_t, w)[0]; else return __builtin_bit_cast(float, w << 16);
+}
+template <bool H16> __device__ __forceinline__ float unpack16_hi(uint32_t w)
+{
+    if constexpr (H16) return (float)__builtin_bit_cast(f16x2_t, w)[1]; else return __builtin_bit_cast(float, w & 0xffff0000u);
+}
+template <bool H16> __device__ __forceinline__ f32x4 mma16(const bf16x8 a, const bf16x8 b, const f32x4 c)
+{
+    if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // max(a, b) for finite operands without the sNaN-quieting v_max the compiler puts in front of fmaxf (one instruction, not two)
 __device__ __forceinline__ float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // two floats -> two OCP e4m3 codes (RNE, saturating at +-448) merged into the low / high half of `old`
@@ -137,7 +162,7 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // 27 % fewer LDS bytes per FLOP -- was bit-identical and ran the 26x26 K-step in 0.99 us, the same as the 176 x 32 forms: every
 // variant lands on ~1.45 PFLOP/s, the rate the chip sustains on random bf16 operands once its clock management has reacted (the
 // CDNA4 guide's 'DVFS give-back': a cycle saved in an MFMA-dense main loop comes back partly as a lower clock).)
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -149,6 +174,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
     static_assert(BK == 64 || BK == 32, "K-step");
     static_assert(EB == 2 || (EB == 1 && BK == 64), "fp8 operands need the 128-B-row form");
+    static_assert(!H16 || EB == 2, "fp16 is a 16-bit storage type");
     constexpr int RB = BK * 2;                 // bytes of one LDS tile row (one K-step of one pixel / filter)
     constexpr int EPC = 16 / EB;               // elements per 16-B chunk
     constexpr int BKE = RB / EB;               // K elements per step
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 const int kk = g / TP, j = g - kk * TP;
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][i], fx[g], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<H16>(fw[kk][i], fx[g], acc[i][j]);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, TC + (W1_UPFRONT ? TC : 0) + PD, 0);
 #pragma unroll
@@ -690,7 +716,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         constexpr int NT = 64 * NTOT;
         constexpr int CPR = BC / 8, NIT = (BP * CPR + NT - 1) / NT;       // bf16 pieces per row / per thread
         constexpr int CPR8 = BC / 16, NIT8 = (BP * CPR8 + NT - 1) / NT;   // fp8 pieces
-        const bool out8 = a.out_dt == DT_FP8;
+        const bool out8 = !H16 && a.out_dt == DT_FP8;            // (an fp16 network has no e4m3 tensors)
         const unsigned osz = out8 ? 1u : 2u;                  // bytes per stored element
         const char *__restrict__ res = (const char *)a.res;
         const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc((char *)a.out + (m0 * a.out_stride + (size_t)ct * BC) * osz);
@@ -749,8 +775,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], t[q]);
                 uint2 pk;
-                pk.x = f32x2_to_bf16x2(v[0], v[1]);
-                pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                pk.x = pack16x2<H16>(v[0], v[1]);
+                pk.y = pack16x2<H16>(v[2], v[3]);
                 *(uint2 *)(smem + (HALO ? prow[j] : ((wpi * TP + j) * 16 + l15) * RS) + chl * 2) = pk;
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (one straight-line block of TC * TP sub-tiles otherwise)
             }
@@ -882,9 +908,9 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         const u32x4_t r = rpre[it];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float lo = __builtin_bit_cast(float, o[q] << 16) + __builtin_bit_cast(float, r[q] << 16);
-                            const float hi = __builtin_bit_cast(float, o[q] & 0xffff0000u) + __builtin_bit_cast(float, r[q] & 0xffff0000u);
-                            o[q] = f32x2_to_bf16x2(lo, hi);
+                            const float lo = unpack16_lo<H16>(o[q]) + unpack16_lo<H16>(r[q]);
+                            const float hi = unpack16_hi<H16>(o[q]) + unpack16_hi<H16>(r[q]);
+                            o[q] = pack16x2<H16>(lo, hi);
                         }
                         if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
@@ -914,7 +940,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         const f32x4 u = v * slope2;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], u[q]);
-                        *(uint2 *)(st2 + (j * 16 + l15) * RS2 + ((t2g * T2W + t) * 16 + lq * 4) * 2) = uint2{f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3])};
+                        *(uint2 *)(st2 + (j * 16 + l15) * RS2 + ((t2g * T2W + t) * 16 + lq * 4) * 2) = uint2{pack16x2<H16>(v[0], v[1]), pack16x2<H16>(v[2], v[3])};
                     };
                     const int j0 = (TP * t2p) / T2P, j1 = (TP * (t2p + 1)) / T2P;       // this wave's pixel sub-tiles
                     // Two sub-tiles at a time: 2 T2W independent accumulation chains, each K-ordered; the loop stays rolled so the fragment
@@ -933,8 +959,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                                 const bf16x8 xb = *(const bf16x8 *)(smem + ((j + 1) * 16 + l15) * RS + (kk * 4 + lq) * 16);
 #pragma unroll
                                 for (int t = 0; t < T2W; ++t) {
-                                    ca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], xa, ca[t], 0, 0, 0);
-                                    cb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], xb, cb[t], 0, 0, 0);
+                                    ca[t] = mma16<H16>(fw2[t][kk], xa, ca[t]);
+                                    cb[t] = mma16<H16>(fw2[t][kk], xb, cb[t]);
                                 }
                             }
 #pragma unroll
@@ -948,7 +974,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                             for (int kk = 0; kk < K2S; ++kk) {
                                 const bf16x8 x = *(const bf16x8 *)(smem + (j * 16 + l15) * RS + (kk * 4 + lq) * 16);
 #pragma unroll
-                                for (int t = 0; t < T2W; ++t) cc_[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][kk], x, cc_[t], 0, 0, 0);
+                                for (int t = 0; t < T2W; ++t) cc_[t] = mma16<H16>(fw2[t][kk], x, cc_[t]);
                             }
 #pragma unroll
                             for (int t = 0; t < T2W; ++t) finish(cc_[t], j, t);

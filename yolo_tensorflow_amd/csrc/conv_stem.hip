@@ -27,19 +27,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Both kernels are VALU-issue-bound (two waves per SIMD, ~4 cycles per instruction): the epilogues are written for instruction count.
 typedef __bf16 st_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float st_f32x2 __attribute__((ext_vector_type(2)));
-// two floats -> packed bf16 pair (lo | hi << 16), one v_cvt_pk_bf16_f32 (RNE)
-__device__ __forceinline__ uint32_t stem_pk(float lo, float hi)
+typedef _Float16 st_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+// two floats -> packed 16-bit pair (lo | hi << 16), RNE: bf16 (one v_cvt_pk_bf16_f32) or, H16, fp16 saturating at +-65504
+template <bool H16> __device__ __forceinline__ uint32_t stem_pk(float lo, float hi)
 {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_bf16x2));
+    if constexpr (H16) {
+        lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f); hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_f16x2));
+    } else return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_bf16x2));
 }
+template <bool H16> __device__ __forceinline__ float stem_lo(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(st_f16x2, w)[0]; else return __builtin_bit_cast(float, w << 16); }
+template <bool H16> __device__ __forceinline__ float stem_hi(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(st_f16x2, w)[1]; else return __builtin_bit_cast(float, w & 0xffff0000u); }
 // max for finite operands as ONE instruction (fmaxf is preceded by an sNaN-quieting v_max)
 __device__ __forceinline__ float stem_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // acc + bias, activation (slope 0.1: leaky as max(v, 0.1 v); slope 1: linear), rounded to bf16: four channels as two packed words
-__device__ __forceinline__ uint2 stem_epi(const f32x4 acc, const f32x4 bias, const float slope)
+template <bool H16> __device__ __forceinline__ uint2 stem_epi(const f32x4 acc, const f32x4 bias, const float slope)
 {
     f32x4 v = acc + bias;
     const f32x4 t = v * slope;
-    return uint2{stem_pk(stem_max(v[0], t[0]), stem_max(v[1], t[1])), stem_pk(stem_max(v[2], t[2]), stem_max(v[3], t[3]))};
+    return uint2{stem_pk<H16>(stem_max(v[0], t[0]), stem_max(v[1], t[1])), stem_pk<H16>(stem_max(v[2], t[2]), stem_max(v[3], t[3]))};
+}
+template <bool H16> __device__ __forceinline__ f32x4 stem_mma(const bf16x8 a, const bf16x8 b, const f32x4 c)
+{
+    if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(st_f16x8, a), __builtin_bit_cast(st_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 constexpr int ST_TH = 8, ST_TW = 16;                 // layer-1 output tile
@@ -67,6 +79,7 @@ constexpr int ST_B1_BYTES = 64 * 4;                          // layer-1 bias: re
 constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
                                                              // would make hipcc wait vmcnt(0) and drain the input prefetch
 
+template <bool H16>
 __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 for (int i = 0; i < 2; ++i) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[i][kk], fx[kk], acc, 0, 0, 0);
-                    uint2 pk = stem_epi(acc, b0v[i], slope0);
+                    for (int kk = 0; kk < 3; ++kk) acc = stem_mma<H16>(fw0[i][kk], fx[kk], acc);
+                    uint2 pk = stem_epi<H16>(acc, b0v[i], slope0);
                     if (!inside) pk = uint2{0, 0};               // layer 1's zero padding, and the unused tail rows
                     *(uint2 *)(l0 + idx * ST_PITCH + (i * 16 + lq * 4) * 2) = pk;
                 }
@@ -174,12 +187,12 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             const int kh = t / 3, kw = t - kh * 3;
             const bf16x8 x = *(const bf16x8 *)(xb + (kh * ST_LW + kw) * ST_PITCH);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[ct][t], x, acc1[ct], 0, 0, 0);
+            for (int ct = 0; ct < 4; ++ct) acc1[ct] = stem_mma<H16>(fw1[ct][t], x, acc1[ct]);
         }
         // ---- epilogue: bias + activation -> bf16 -> LDS -> 16-B stores ----
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi(acc1[ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc1[ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
         }
         // staged tile complete, every wave done with the layer-0 tile, and the next tile's input has landed
         __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
@@ -202,13 +215,13 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const bf16x8 w = *(const bf16x8 *)(lw2 + (i * 16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc2[i], 0, 0, 0);
+                    acc2[i] = stem_mma<H16>(w, x, acc2[i]);
                 }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x4 bv = *(const f32x4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4);
-                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi(acc2[i], bv, slope2);
+                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[i], bv, slope2);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
@@ -259,6 +272,7 @@ constexpr int HL_INCHUNKS = (HL_INPIX * 4 + 63) / 64;        // 16-B pieces / 64
 constexpr int HL_IN_BYTES = HL_INCHUNKS * 1024;
 constexpr int HL_RES_BYTES = ST_TH * ST_TW * 128;            // shortcut tile [128 px][64 bf16], lane-linear
 
+template <bool H16>
 __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -331,11 +345,11 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
             const int p = (wave + kh) * HL_IW + l15 + kw;        // input-tile pixel of this lane for this tap
             const bf16x8 x = *(const bf16x8 *)(in_cur + p * 64 + ((lq ^ (2 * ((p >> 2) & 1))) << 4));
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct][t], x, acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = stem_mma<H16>(fw[ct][t], x, acc[ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi(acc[ct], bv[ct], slope);
+            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc[ct], bv[ct], slope);
         }
         // staged tile complete, every wave done with this tile's input, next input and this tile's shortcut have landed
         __builtin_amdgcn_s_waitcnt(0x0070);
@@ -351,9 +365,9 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
                 uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rv[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float lo_ = __builtin_bit_cast(float, ov[q] << 16) + __builtin_bit_cast(float, rv[q] << 16);
-                    const float hi_ = __builtin_bit_cast(float, ov[q] & 0xffff0000u) + __builtin_bit_cast(float, rv[q] & 0xffff0000u);
-                    ov[q] = stem_pk(lo_, hi_);
+                    const float lo_ = stem_lo<H16>(ov[q]) + stem_lo<H16>(rv[q]);
+                    const float hi_ = stem_hi<H16>(ov[q]) + stem_hi<H16>(rv[q]);
+                    ov[q] = stem_pk<H16>(lo_, hi_);
                 }
                 o = uint4{ov[0], ov[1], ov[2], ov[3]};
             }
@@ -384,24 +398,26 @@ bool conv_halo_ok(const HaloArgs &a)
     // 32-bit buffer offsets below 0x80000000 (the out-of-range sentinel): input and shortcut windows must stay under 2 GiB
     const double px = (double)a.N * a.H * a.W;
     if (px * a.in_stride * 2.0 >= 2147483648.0 || (a.res && px * a.res_stride * 2.0 >= 2147483648.0)) return false;
-    return a.Cin == 32 && a.Cout == 64 && a.Kpad >= 288 && (a.in_stride % 8) == 0 && a.in_stride >= 32 && (a.out_stride % 8) == 0 &&
+    return (a.dt == DT_BF16 || a.dt == DT_F16) && a.Cin == 32 && a.Cout == 64 && a.Kpad >= 288 && (a.in_stride % 8) == 0 && a.in_stride >= 32 && (a.out_stride % 8) == 0 &&
            a.out_stride >= 64 && (!a.res || ((a.res_stride % 8) == 0 && a.res_stride >= 64));
 }
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s)
 {
     if (!conv_halo_ok(a)) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * HL_IN_BYTES + HL_RES_BYTES + ST_OUT_BYTES;
-    { hipError_t e = conv_opt_in_lds((const void *)conv_halo_c32_c64, lds); if (e != hipSuccess) return e; }
+    const bool h16 = a.dt == DT_F16;
+    { hipError_t e = conv_opt_in_lds(h16 ? (const void *)conv_halo_c32_c64<true> : (const void *)conv_halo_c32_c64<false>, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.W + ST_TW - 1) / ST_TW) * ((a.H + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;
-    hipLaunchKernelGGL(conv_halo_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    if (h16) hipLaunchKernelGGL(conv_halo_c32_c64<true>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    else hipLaunchKernelGGL(conv_halo_c32_c64<false>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
     return hipGetLastError();
 }
 
 bool conv_stem_ok(const StemArgs &a)
 {
     if ((double)a.N * a.H * a.W * a.in_stride * 2.0 >= 2147483648.0) return false;       // 32-bit buffer offsets, see conv_halo_ok
-    return a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&
+    return (a.dt == DT_BF16 || a.dt == DT_F16) && a.C0 == 32 && a.C1 == 64 && a.in_stride == 8 && a.Kpad0 >= 96 && a.Kpad1 >= 288 && (a.out_stride % 8) == 0 && a.out_stride >= 64 &&
            a.Ho == (a.H + 2 - 3) / 2 + 1 && a.Wo == (a.W + 2 - 3) / 2 + 1 &&
            (!a.w2 || (a.C2 == 32 && a.Kpad2 >= 64 && a.out2 && (a.out2_stride % 8) == 0 && a.out2_stride >= 32));
 }
@@ -410,9 +426,11 @@ hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES + ST_B1_BYTES;
-    { hipError_t e = conv_opt_in_lds((const void *)conv_stem_c32_c64, lds); if (e != hipSuccess) return e; }
+    const bool h16 = a.dt == DT_F16;
+    { hipError_t e = conv_opt_in_lds(h16 ? (const void *)conv_stem_c32_c64<true> : (const void *)conv_stem_c32_c64<false>, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
-    hipLaunchKernelGGL(conv_stem_c32_c64, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    if (h16) hipLaunchKernelGGL(conv_stem_c32_c64<true>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    else hipLaunchKernelGGL(conv_stem_c32_c64<false>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
     return hipGetLastError();
 }

@@ -33,6 +33,28 @@ template <> struct Elt<bf16_t> {
     static __device__ __forceinline__ float load1(const bf16_t *p) { return __builtin_bit_cast(float, (uint32_t)(*p) << 16); }
     static __device__ __forceinline__ void store1(bf16_t *p, float f) { *p = (bf16_t)cvt(f); }
 };
+template <> struct Elt<f16_t> {       // IEEE binary16: decode exact, encode round-to-nearest-even, saturating at +-65504 (as the conv epilogues do)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void load8(const f16_t *p, float *v)
+    {
+        uint4 u = *(const uint4 *)p;
+        uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const h2 h = __builtin_bit_cast(h2, w[i]); v[2 * i] = (float)h[0]; v[2 * i + 1] = (float)h[1]; }
+    }
+    static __device__ __forceinline__ uint32_t pk(float a, float b)
+    {
+        a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, h2));
+    }
+    static __device__ __forceinline__ void store8(f16_t *p, const float *v)
+    {
+        *(uint4 *)p = uint4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
+    }
+    static __device__ __forceinline__ float load1(const f16_t *p) { return (float)__builtin_bit_cast(_Float16, p->b); }
+    static __device__ __forceinline__ void store1(f16_t *p, float f) { p->b = (uint16_t)(pk(f, 0.f) & 0xffffu); }
+};
 template <> struct Elt<float> {
     static __device__ __forceinline__ void load8(const float *p, float *v)
     {
@@ -78,6 +100,7 @@ template <> struct Elt<fp8_t> {      // OCP e4m3: decode is exact, encode is rou
     do {                                                                         \
         if ((dt) == DT_F32) { typedef float T; __VA_ARGS__; }                    \
         else if ((dt) == DT_FP8) { typedef fp8_t T; __VA_ARGS__; }               \
+        else if ((dt) == DT_F16) { typedef f16_t T; __VA_ARGS__; }               \
         else { typedef bf16_t T; __VA_ARGS__; }                                  \
     } while (0)
 

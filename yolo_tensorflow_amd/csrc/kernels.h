@@ -5,7 +5,8 @@
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
 struct fp8_t { uint8_t b; };   // raw OCP e4m3 (e4m3fn) bits in HBM
-enum { DT_BF16 = 0, DT_F32 = 1, DT_FP8 = 2 };
+struct f16_t { uint16_t b; };  // raw IEEE binary16 bits in HBM
+enum { DT_BF16 = 0, DT_F32 = 1, DT_FP8 = 2, DT_F16 = 3 };
 inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_FP8 ? 1 : 2; }
 #define FP8_MAX 448.0f
 
@@ -109,6 +110,7 @@ struct StemArgs {
     const void *w0; const float *b0; int Kpad0, C0, act0;    // layer 0: [C0 pad][Kpad0], k = tap*8 + ci
     const void *w1; const float *b1; int Kpad1, C1, act1;    // layer 1: [C1 pad][Kpad1], k = tap*C0 + ci
     void *out; int out_stride;                // [N,Ho,Wo,C1] bf16
+    int dt;                                   // DT_BF16 or DT_F16: the 16-bit storage type of every tensor and filter of the launch
     // optional tail: a 1x1/s1 conv C1 -> C2 = 32 on the freshly produced layer-1 tile (darknet-53 layer 2); w2 == nullptr: none
     const void *w2; const float *b2; int Kpad2, C2, act2;    // [C2 pad][Kpad2], k = ci
     void *out2; int out2_stride;              // [N,Ho,Wo,C2] bf16
@@ -124,6 +126,7 @@ struct HaloArgs {
     const void *res; int res_stride;          // shortcut source [N,H,W,>=64] bf16 or nullptr
     void *out; int out_stride;
     int N, H, W;
+    int dt;                                   // DT_BF16 or DT_F16
 };
 bool conv_halo_ok(const HaloArgs &a);
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s);

@@ -110,7 +110,8 @@ struct yolo_ctx {
     // layer i (1 by default); eff_scale[i] is the scale of the tensor layer i's view holds (inherited through
     // upsample / maxpool / reorg / single-input route; NaN for multi-input routes, which are per channel).
     std::vector<float> user_scale, eff_scale;
-    int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : DT_BF16; }
+    int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : dtype == YOLO_FP16 ? DT_F16 : DT_BF16; }
+    bool half_like() const { return dtype == YOLO_BF16 || dtype == YOLO_FP16; }      // 16-bit storage: the same kernels, the same plan
     int gran() const { return dtype == YOLO_FP8 ? 16 : 8; }            // channel granule = one 16-B piece (8 for fp32 too)
     size_t esize() const { return dt_size(act_dt()); }
 };
@@ -136,6 +137,26 @@ uint16_t f2bf(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// float -> IEEE binary16 bits: round to nearest even, saturating at +-65504 (as the device's conversions do), NaN stays NaN
+uint16_t f2h(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    if (f != f) return (uint16_t)(sign | 0x7e00u);
+    float a = fabsf(f);
+    if (a >= 65504.f) return (uint16_t)(sign | 0x7bffu);
+    if (a < ldexpf(1.f, -24) * 0.5f) return sign;                       // below half the smallest subnormal (ties to even: zero)
+    int e; frexpf(a, &e); e -= 1;                                         // a in [2^e, 2^(e+1))
+    if (e < -14) e = -14;                                                 // subnormals share the first binade's quantum
+    const float quantum = ldexpf(1.f, e - 10);
+    const float q = nearbyintf(a / quantum);                              // exact division, RNE under the default rounding mode
+    const float v = q * quantum;
+    if (v < ldexpf(1.f, -14)) return (uint16_t)(sign | (uint16_t)q);      // subnormal: q in 0..1023
+    int e2; frexpf(v, &e2); e2 -= 1;
+    const int m = (int)((v / ldexpf(1.f, e2) - 1.f) * 1024.f);
+    return (uint16_t)(sign | ((e2 + 15) << 10) | m);
 }
 
 // float -> OCP e4m3 (e4m3fn) code: round to nearest even, saturate at +-448, NaN -> 0x7f
@@ -318,7 +339,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     }
     // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
     // (the stem and halo kernels address their input with 32-bit buffer offsets: the whole-batch window must stay under 2 GiB)
-    if (c->dtype == YOLO_BF16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
+    if (c->half_like() && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
         const Layer &A = c->layers[0], &B = c->layers[1];
         if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
             A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1) {
@@ -330,7 +351,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             }
         }
     }
-    if (c->dtype == YOLO_BF16 && !getenv("YOLO_NO_HALO"))
+    if (c->half_like() && !getenv("YOLO_NO_HALO"))
         for (int i = 1; i < NL; ++i) {
             Layer &L = c->layers[i];
             if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64)
@@ -338,7 +359,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
-    if ((c->dtype == YOLO_BF16 || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
+    if ((c->half_like() || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
             if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
@@ -445,7 +466,7 @@ int allocate(yolo_ctx *c)
         L.out.ptr = (char *)c->phys[s.phys] + (size_t)L.ch_off * dt_size(s.dt);
     }
     // network input: 3 real channels padded to 8
-    c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : DT_BF16;            // fp8 mode keeps the image in bf16
+    c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : c->dtype == YOLO_FP16 ? DT_F16 : DT_BF16;            // fp8 mode keeps the image in bf16
     size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 8 * dt_size(c->input.dt);
     HIPCK(c, hipMalloc(&c->input.ptr, in_bytes));
     c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8;
@@ -549,7 +570,7 @@ int run_layer(yolo_ctx *c, int i, int n)
                 const Layer &T = c->layers[i + 1];
                 t.w2 = T.d_w; t.b2 = T.d_b; t.Kpad2 = T.kpad; t.C2 = T.filters; t.act2 = T.act; t.out2 = T.out.ptr; t.out2_stride = T.out.stride;
             }
-            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros;
+            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros; t.dt = c->act_dt();
             HIPCK(c, launch_conv_stem(t, s));
             break;
         }
@@ -559,7 +580,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         if (L.halo) {          // small-Cin 3x3: input tile staged once in LDS (conv_stem.hip)
             HaloArgs h; memset(&h, 0, sizeof h);
             h.in = a.in; h.in_stride = a.in_stride; h.w = a.wt; h.b = a.bias; h.Kpad = a.Kpad; h.Cin = L.cin; h.Cout = L.filters; h.act = L.act;
-            h.res = a.res; h.res_stride = a.res_stride; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = L.H; h.W = L.W;
+            h.res = a.res; h.res_stride = a.res_stride; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = L.H; h.W = L.W; h.dt = L.in_dt;
             if (conv_halo_ok(h)) { HIPCK(c, launch_conv_halo(h, s)); break; }
             // window over 2 GiB (very large batches): the tiled kernel below checks its own window
         }
@@ -760,7 +781,7 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int
                 const size_t idx = (size_t)o * L.kpad + ((size_t)(ci / kc) * k * k + t) * kc + ci % kc;     // t = kh * k + kw
                 if (wdt == DT_F32) memcpy(&wbuf[idx * 4], &v, 4);
                 else if (wdt == DT_FP8) wbuf[idx] = f2e4m3(v / osc[o]);
-                else { uint16_t b = f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
+                else { uint16_t b = wdt == DT_F16 ? f2h(v) : f2bf(v); memcpy(&wbuf[idx * 2], &b, 2); }
             }
     }
 }
@@ -806,7 +827,7 @@ yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
     auto bail = [&](yolo_ctx *c, const std::string &m) -> yolo_ctx * { if (err && err_len) snprintf(err, err_len, "%s", m.c_str()); if (c) yolo_destroy(c); return nullptr; };
     if (!cfg || cfg->struct_size != sizeof(yolo_config)) return bail(nullptr, "yolo_create: bad yolo_config (struct_size)");
     if (cfg->max_batch < 1) return bail(nullptr, "yolo_create: max_batch < 1");
-    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32 && cfg->dtype != YOLO_FP8) return bail(nullptr, "yolo_create: dtype");
+    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32 && cfg->dtype != YOLO_FP8 && cfg->dtype != YOLO_FP16) return bail(nullptr, "yolo_create: dtype");
     yolo_ctx *c = new yolo_ctx();
     c->device = cfg->device; c->max_batch = cfg->max_batch; c->dtype = cfg->dtype; c->semantics = cfg->semantics;
     c->decode = cfg->decode; c->keep_layers = cfg->keep_layers;
@@ -863,7 +884,7 @@ int yolo_set_act_scales(yolo_ctx *c, const float *scales, int n)
 // the device, so both ways of loading parameters (weight stream, export artifact) share it.
 static int tail_fragments(yolo_ctx *c)
 {
-    if (c->dtype != YOLO_BF16) return YOLO_OK;
+    if (!c->half_like()) return YOLO_OK;
     std::vector<uint16_t> src, dst;
     for (auto &T : c->layers) {
         if (T.type != L_CONV || T.fused_into < 0) continue;
@@ -1545,7 +1566,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     if (!x || !w_hwio || !out || n < 1 || (k != 1 && k != 3) || stride < 1) { g_op_err = "conv2d: bad arguments"; return YOLO_ERR_INVALID; }
     OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
     // dtype YOLO_FP8: x, residual and the result are e4m3 tensors of scale 1 (the inputs are quantised here first)
-    const bool f32 = dtype == YOLO_FP32; const int dt = f32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : DT_BF16; const size_t es = dt_size(dt);
+    const bool f32 = dtype == YOLO_FP32; const int dt = f32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : dtype == YOLO_FP16 ? DT_F16 : DT_BF16; const size_t es = dt_size(dt);
     const int gr = dt == DT_FP8 ? 16 : 8;
     Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act; L.in_dt = dt;
     L.cin = cin; L.cin_pad = roundup(cin, gr); L.kpad = roundup(k * k * L.cin_pad, dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(cout, 256);
@@ -1580,7 +1601,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     conv_finalize(a);
     if (conv_cfg_is_halo(tile_cfg) && (f32 || !conv_halo13_ok(a))) { g_op_err = "conv2d: tile config not applicable to this shape (halo-staged form: 3x3, stride 1, size a multiple of 13, whole channel chunks)"; return YOLO_ERR_UNSUPPORTED; }
     hipError_t e;
-    if (dt != DT_F32 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
+    if (dt != DT_F32 && dt != DT_F16 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build (YOLO_CONV_DIAG=free: of the free-running halo form
         // f176c256), printed to stderr
         const bool dwide = !strcmp(getenv("YOLO_CONV_DIAG"), "free4");        // four waves of 176 x 64
