@@ -26,6 +26,8 @@ def test_rccl_gather_of_device_records_world1(hiplib):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         rccl_check.run_check(rank=0, world=1, local_rank=0)
+        ms_raw, ms_rec = rccl_check.run_stress(rank=0, world=1, local_rank=0, global_batch=4, iters=3)      # the fabric stress mode's code path
+        assert ms_raw > 0 and ms_rec > 0
     finally:
         dist.destroy_process_group()
 

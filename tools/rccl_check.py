@@ -4,6 +4,12 @@ box records written in place by the library), then ONE all_gather_into_tensor of
 produces for the whole batch.
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/rccl_check.py
+
+Fabric stress mode (the raw-tensor all-gather used to MEASURE xGMI, never on the product path): every rank
+contributes its [B/G, rows, 85] bf16 decoded tensor (YOLOv3 416: 10647 rows -> 1.8 MB per image) to one all_gather_into_tensor;
+prints bytes, time and the per-link rate of a ring over xGMI (7 links x ~153 GB/s per GPU), next to the box-record exchange:
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29611 tools/rccl_check.py --stress [--batch 64] [--iters 20]
 """
 import os
 import sys
@@ -58,13 +64,59 @@ def run_check(rank, world, local_rank, n_local=4, size=160, max_out=10):
     return True
 
 
+def run_stress(rank, world, local_rank, global_batch=64, rows=10647, attrs=85, iters=20, max_out=20):
+    """All-gather of the raw bf16 decoded tensors (what a naive multi-GPU detector would exchange) against the 24-byte box records the
+    product exchanges: one line per rank 0 with both timings.  Data is random: this measures the fabric, not the network."""
+    import torch
+    import torch.distributed as dist
+    from yolo_tensorflow_amd import dist as ydist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lo, hi = ydist.shard_bounds(global_batch, world, rank)
+    per = -(-global_batch // world)
+    local = torch.randn((per, rows, attrs), device=dev).to(torch.bfloat16)
+    out = torch.empty((world * per, rows, attrs), dtype=torch.bfloat16, device=dev)
+    rec, _, _ = ydist.alloc_flat_records(per, max_out, dev)
+    rec_all = torch.empty((world, rec.numel()), dtype=rec.dtype, device=dev)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        t = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ms_raw = timed(lambda: dist.all_gather_into_tensor(out, local))
+    ms_rec = timed(lambda: dist.all_gather_into_tensor(rec_all, rec))
+    # every rank holds every rank's block afterwards
+    chk = torch.stack([out[r * per] .float().abs().sum() for r in range(world)])
+    assert torch.isfinite(chk).all() and (chk > 0).all()
+    if rank == 0:
+        raw_bytes = local.numel() * 2
+        # ring all-gather: every GPU sends (and receives) (world - 1) blocks over its ring link
+        per_link = (world - 1) * raw_bytes / (ms_raw * 1e-3) / 1e9 if world > 1 else 0.0
+        print("rccl_check stress: world %d, global batch %d | raw decoded tensors: %.1f MB per rank, all-gather %.3f ms (%.1f GB/s per ring "
+              "link; xGMI link ~153 GB/s) | box records: %d B per rank, all-gather %.3f ms" % (world, global_batch, raw_bytes / 1e6, ms_raw, per_link, rec.numel() * 4, ms_rec))
+    return ms_raw, ms_rec
+
+
 if __name__ == "__main__":
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lr = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lr))
-    run_check(rank, world, lr)
+    if "--stress" in sys.argv:
+        arg = lambda k, d: int(sys.argv[sys.argv.index(k) + 1]) if k in sys.argv else d
+        run_stress(rank, world, lr, global_batch=arg("--batch", 64), iters=arg("--iters", 20))
+    else:
+        run_check(rank, world, lr)
     dist.barrier(); dist.destroy_process_group()
     if rank == 0:
         print("rccl_check ok: world %d" % world)
