@@ -83,6 +83,10 @@ def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=Non
     NL = len(layers)
     user = np.ones(NL, np.float32) if scales is None else np.asarray(scales, np.float32)
     codes = [None] * NL; chs = [None] * NL       # e4m3 code values, per-channel scale vectors
+    # mixed plans: a [convolutional] section with `yolo_store=bf16` keeps its output -- and what is derived from it without arithmetic --
+    # in bf16 (scale 1; `codes` then holds the bf16 values themselves); a conv whose input is stored in bf16 runs as the first conv does
+    # (bf16 filters, bf16 MFMA)
+    is16 = [False] * NL
     outs, heads = [], []
     x = to_bf16(np.asarray(x, dtype=np.float32))
     ci = 0
@@ -95,6 +99,8 @@ def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=Non
             w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
             if i == 0:
                 y = conv2d_nhwc(x, to_bf16(w), st) + b
+            elif is16[i - 1]:
+                y = conv2d_nhwc(codes[i - 1], to_bf16(w), st) + b
             else:
                 cx, sx = codes[i - 1], chs[i - 1]
                 weff = (w * sx[None, None, :, None]).astype(np.float32)             # HWIO
@@ -111,10 +117,26 @@ def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=Non
             y = y.astype(np.float32)
             if is_head:
                 outs.append(y); continue
+            if s.get("yolo_store", "fp8") == "bf16":
+                is16[i] = True
+                codes[i] = to_bf16(y); chs[i] = np.ones(y.shape[-1], np.float32)
+                outs.append(codes[i])
+                if teacher is not None and teacher[i] is not None:
+                    codes[i] = to_bf16(np.asarray(teacher[i], np.float32))
+                continue
             inv = f32(1.0) / user[i]
             codes[i] = to_fp8_e4m3(to_bf16(y) * inv); chs[i] = np.full(codes[i].shape[-1], user[i], np.float32)
         elif t == "shortcut":
             f = int(s["from"]); f = f if f >= 0 else i + f
+            if is16[i - 1] != is16[f]:
+                raise ValueError("layer %d: shortcut operands stored in different types" % i)
+            if is16[f]:
+                is16[i] = True
+                codes[i] = to_bf16(codes[i - 1] + codes[f]); chs[i] = np.ones(codes[i].shape[-1], np.float32)
+                outs.append(codes[i])
+                if teacher is not None and teacher[i] is not None:
+                    codes[i] = to_bf16(np.asarray(teacher[i], np.float32))
+                continue
             sa, sb = chs[i - 1][0], chs[f][0]
             inv = f32(1.0) / user[i]
             codes[i] = to_fp8_e4m3(((codes[i - 1] * sa).astype(np.float32) + (codes[f] * sb).astype(np.float32)).astype(np.float32) * inv)
@@ -122,25 +144,30 @@ def fp8_scheme_forward(secs, params, x, scales=None, semantics="tf", teacher=Non
         elif t == "route":
             ls = [int(v) for v in s["layers"].split(",")]
             ls = [l if l >= 0 else i + l for l in ls]
+            if len({is16[l] for l in ls}) > 1:
+                raise ValueError("layer %d: route inputs stored in different types" % i)
+            is16[i] = is16[ls[0]]
             codes[i] = np.concatenate([codes[l] for l in ls], axis=-1) if len(ls) > 1 else codes[ls[0]]
             chs[i] = np.concatenate([chs[l] for l in ls]) if len(ls) > 1 else chs[ls[0]]
         elif t == "upsample":
-            codes[i] = to_fp8_e4m3(upsample_tf(codes[i - 1])) if semantics == "tf" else upsample_nearest(codes[i - 1], int(s.get("stride", 2)))
+            is16[i] = is16[i - 1]
+            rnd = to_bf16 if is16[i] else to_fp8_e4m3
+            codes[i] = rnd(upsample_tf(codes[i - 1])) if semantics == "tf" else upsample_nearest(codes[i - 1], int(s.get("stride", 2)))
             chs[i] = chs[i - 1]
         elif t == "maxpool":
             st = int(s.get("stride", 1)); k = int(s.get("size", st))
-            codes[i] = max_pool(codes[i - 1], k, st, int(s.get("padding", (k - 1) // 2))); chs[i] = chs[i - 1]
+            codes[i] = max_pool(codes[i - 1], k, st, int(s.get("padding", (k - 1) // 2))); chs[i] = chs[i - 1]; is16[i] = is16[i - 1]
         elif t == "reorg":
             st = int(s.get("stride", 1))
             codes[i] = space_to_depth(codes[i - 1], st) if semantics == "tf" else reorg_darknet(codes[i - 1], st)
-            chs[i] = np.full(codes[i].shape[-1], chs[i - 1][0], np.float32)
+            chs[i] = np.full(codes[i].shape[-1], chs[i - 1][0], np.float32); is16[i] = is16[i - 1]
         elif t in ("yolo", "region"):
             heads.append((s, outs[i - 1])); outs.append(None); continue
         else:
             raise ValueError(t)
         outs.append((codes[i] * chs[i]).astype(np.float32))
         if teacher is not None and teacher[i] is not None and not (t == "route" and len(ls) > 1):
-            codes[i] = to_fp8_e4m3(np.asarray(teacher[i], np.float32) / chs[i])
+            codes[i] = to_bf16(np.asarray(teacher[i], np.float32)) if is16[i] else to_fp8_e4m3(np.asarray(teacher[i], np.float32) / chs[i])
     return heads, outs
 
 

@@ -142,3 +142,76 @@ def test_fp8_tracks_full_precision(hiplib):
     with pytest.raises(hiplib.YoloError):
         eng.forward(img) if False else hiplib.Engine(txt, dtype=hiplib.BF16).set_act_scales(np.ones(eng.num_layers, np.float32))
     eng.close()
+
+
+def test_mixed_e4m3_bf16_plan_vs_emulation(hiplib):
+    """Mixed-precision plans (cfg key yolo_store=bf16 on [convolutional] sections of an fp8 network, darknet_io.with_layer_store): the
+    13x13 stage and the FPN blocks keep bf16 tensors and run on the bf16 MFMA, the backbone up to 26x26 stays e4m3.  Every layer under
+    teacher forcing against the oracle's emulation of the same plan: e4m3 layers to the code (as above), bf16 layers to a bf16 ulp;
+    the closure rule (one storage type per residual stream / concatenation) is enforced by the library; fused == unfused."""
+    size = 96
+    txt0 = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs0 = IO.parse_cfg(txt0); flat = IO.synth_weights(secs0, seed=0)
+    convs = [i for i, s in enumerate(secs0[1:]) if s["type"] == "convolutional"]
+    heads_in = [i for i in convs if secs0[1:][i + 1]["type"] == "yolo"]
+    want = [i for i in convs if i >= 62 and i not in heads_in]
+    with pytest.raises(hiplib.YoloError, match="different types"):
+        hiplib.Engine(IO.with_layer_store(txt0, want), max_batch=2, dtype=hiplib.FP8)          # route 86 would concatenate bf16 and e4m3
+    with pytest.raises(hiplib.YoloError, match="fp8 networks"):
+        hiplib.Engine(IO.with_layer_store(txt0, [5]), max_batch=2, dtype=hiplib.BF16)
+    S = IO.store_closure(secs0, want)
+    assert set(want) < set(S)
+    txt = IO.with_layer_store(txt0, S)
+    img = np.random.default_rng(2).integers(0, 256, (2, size, size, 3), dtype=np.uint8)
+    x01 = img.astype(np.float32) / np.float32(255)
+    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.FP8, keep_layers=True)
+    eng.set_weights(flat)
+    det = eng.forward(img)
+    dev = []
+    for i, s in enumerate(osecs[1:]):
+        multi_route = s["type"] == "route" and "," in s["layers"]
+        dev.append(None if s["type"] in ("yolo", "region") or multi_route else eng.layer_output(i, 2))
+    heads, outs = R.fp8_scheme_forward(osecs, params, x01, teacher=dev)
+    n16 = 0
+    for i, s in enumerate(osecs[1:]):
+        if dev[i] is None:
+            continue
+        is_head = i + 1 < len(osecs) - 1 and osecs[i + 2]["type"] in ("yolo", "region")
+        if is_head:
+            np.testing.assert_allclose(dev[i], outs[i], rtol=2e-3, atol=2e-3 * float(np.abs(outs[i]).max()), err_msg="head conv %d" % i)
+        elif not _stored16(osecs, i):
+            ops = ()
+            if s["type"] == "shortcut":
+                f = int(s["from"]); f = f if f >= 0 else i + f
+                ops = (dev[i - 1], dev[f])
+            _codes_close(dev[i], outs[i], 1.0, "mixed layer %d (%s)" % (i, s["type"]), operands=ops)
+        else:
+            n16 += 1
+            err = np.abs(dev[i] - outs[i]); tol = 2.0 ** -7 * np.maximum(np.abs(outs[i]), np.abs(dev[i])) + 2e-3
+            if s["type"] == "shortcut":
+                f = int(s["from"]); f = f if f >= 0 else i + f
+                tol = 2.0 ** -7 * (np.abs(dev[i - 1]) + np.abs(dev[f])) + 2e-3
+            assert (err <= tol).all(), "bf16-stored layer %d (%s): max err %.3e" % (i, s["type"], err.max())
+    assert n16 > 40
+    eng.close()
+    eng2 = hiplib.Engine(txt, max_batch=2, dtype=hiplib.FP8)
+    eng2.set_weights(flat)
+    assert np.array_equal(eng2.forward(img), det), "fused and unfused mixed plans differ"
+    eng2.close()
+
+
+def _stored16(osecs, i):
+    """is layer i's tensor stored in bf16 under the plan in the cfg text (yolo_store keys + inheritance)?"""
+    L = osecs[1:]
+    t = L[i]["type"]
+    if t == "convolutional":
+        return L[i].get("yolo_store") == "bf16"
+    if t in ("yolo", "region"):
+        return False
+    if t == "shortcut":
+        return _stored16(osecs, i - 1)
+    if t == "route":
+        ls = [int(v) if int(v) >= 0 else i + int(v) for v in L[i]["layers"].split(",")]
+        return _stored16(osecs, ls[0])
+    return _stored16(osecs, i - 1)

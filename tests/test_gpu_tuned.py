@@ -21,7 +21,7 @@ from yolo_tensorflow_amd import darknet_io as IO
 pytestmark = pytest.mark.gpu
 FP8_IOU, FP8_DSCORE = 0.85, 0.03        # measured on MI355X (4910 candidates): min IoU 0.878, max |dscore| 0.021 -- DESIGN.md section 4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PLANS = sorted(glob.glob(os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_*.json")))
+PLANS = sorted(p for p in glob.glob(os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_*.json")) if re.search(r"_(bf16|fp8)\.json$", p))
 
 
 def _iou(a, b):
@@ -171,6 +171,34 @@ def test_config5_fp8_416_b32_full_size(hiplib):
     print("fp8 416 b32, calibrated scales, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, below threshold %d" % (cnt, miou, mds, lost))
     assert cnt > 1000
     assert miou >= FP8_IOU and mds <= FP8_DSCORE
+
+
+MIXED_IOU, MIXED_DSCORE = 0.97, 5e-3
+
+
+def test_config5_mixed_plan_416_b32_vs_oracle(hiplib):
+    """a USABLE accuracy point for the e4m3 configuration.  The committed mixed plan (tuned/yolov3_416_b32_mixed.json:
+    the 13x13 stage and the FPN blocks in bf16, the backbone up to 26x26 in e4m3) on all 32 images against the fp32 oracle, every oracle
+    candidate, no margin; the plan's tile choices are bit-identical to the default ones."""
+    txt0, flat, img = _setup(416, 32)
+    mp = json.load(open(os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_mixed.json")))
+    secs0 = IO.parse_cfg(txt0)
+    assert IO.store_closure(secs0, mp["store_bf16"]) == sorted(mp["store_bf16"])              # the committed list is closed
+    txt = IO.with_layer_store(txt0, mp["store_bf16"])
+    share = IO.bf16_flop_share(IO.parse_cfg(txt))
+    eng = hiplib.Engine(txt, max_batch=32, dtype=hiplib.FP8)
+    eng.set_weights(flat)
+    det = eng.forward(img)
+    if "cfgs" in mp:
+        assert mp["num_cfgs"] == hiplib.op_conv_num_cfgs()
+        eng.set_tile_configs(mp["cfgs"])
+        assert np.array_equal(eng.forward(img), det)
+    eng.close()
+    ref = oracle_detections(txt0, flat, img, 416)
+    miou, mds, cnt, lost = box_deviation(ref, det, 0.0)
+    print("mixed e4m3 / bf16 plan (%.1f %% of the FLOPs on the bf16 MFMA), 416 b32, vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, below threshold %d"
+          % (100 * share, cnt, miou, mds, lost))
+    assert cnt > 1000 and miou >= MIXED_IOU and mds <= MIXED_DSCORE
 
 
 def test_graph_survives_box_buffer_growth(hiplib):

@@ -38,6 +38,7 @@ struct Layer {
     void *d_w = nullptr; float *d_b = nullptr; float *d_sc = nullptr;   // filters, bias, fp8 per-channel dequant scale
     void *d_wf = nullptr;                   // bf16 1x1 conv that can ride in its producer's epilogue: its filters in MFMA-fragment order (tail_fragments)
     int in_dt = DT_BF16;                 // operand type of this conv's MFMA (filters are stored in it)
+    int store_dt = DT_BF16;              // element type of this layer's output tensor (mixed plans: an fp8 network with bf16 islands, cfg key yolo_store)
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
@@ -130,6 +131,7 @@ int fail(yolo_ctx *c, int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(c, YOLO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+inline int gran_of(int dt) { return dt == DT_FP8 ? 16 : 8; }      // channels per 16-byte piece (8 for fp32 tensors too)
 
 uint16_t f2bf(float f)
 {
@@ -237,8 +239,19 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
             if (L.size == 7 && L.stride == 2 && L.pad == 3 && i == 0 && C == 3 && H % 2 == 0 && W % 2 == 0 && c->dtype != YOLO_FP8) L.s2d7 = true;
             else if (L.size != 1 && L.size != 3) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: conv size %d unsupported on the device path", i, L.size);
-            // fp8 mode: the first conv still reads the bf16 image (3 real channels padded to 8) with bf16 filters
-            L.in_dt = c->dtype == YOLO_FP8 ? (i == 0 ? DT_BF16 : DT_FP8) : c->act_dt();
+            // fp8 mode: the first conv still reads the bf16 image (3 real channels padded to 8) with bf16 filters; a conv reads its
+            // producer's tensor in the type that tensor is stored in (cfg key `yolo_store=bf16` on a [convolutional] section of an fp8
+            // network keeps that layer's output -- and what is derived from it without arithmetic -- in bf16: mixed-precision plans)
+            L.in_dt = c->dtype == YOLO_FP8 ? (i == 0 ? DT_BF16 : c->layers[i - 1].store_dt) : c->act_dt();
+            L.store_dt = c->act_dt();
+            {
+                const std::string st = opt_s(s, "yolo_store", "");
+                if (!st.empty()) {
+                    if (c->dtype != YOLO_FP8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: yolo_store is a key of fp8 networks (mixed e4m3 / bf16 plans)", i);
+                    if (st == "bf16") L.store_dt = DT_BF16; else if (st == "fp8") L.store_dt = DT_FP8;
+                    else return fail(c, YOLO_ERR_INVALID, "layer %d: yolo_store=%s (bf16 or fp8)", i, st.c_str());
+                }
+            }
             L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
             L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
             if (L.s2d7) { L.cin_pad = 32; L.kpad = 16 * 32; }          // 4x4 taps x (2x2 positions x 8 padded channels)
@@ -253,7 +266,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             std::string act = opt_s(s, "activation", "logistic");
             if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
             else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
-            L.in_dt = c->act_dt();
+            L.in_dt = c->act_dt(); L.store_dt = c->act_dt();
             if ((long)H * W * C > (1L << 24)) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [connected] input too large", i);
             L.cin = H * W * C; L.cin_pad = roundup(L.cin, 8); L.kpad = roundup(L.cin_pad, 64); L.cout_pad = roundup(L.filters, 256);
             c->conv_flops += 2.0 * L.cin * L.filters;
@@ -322,6 +335,12 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: section [%s] is outside the inference hot path", i, s.type.c_str());
         }
         L.H = H; L.W = W; L.C = C;
+        if (L.type != L_CONV) {
+            // layers that move data keep the type of what they move; their operands must agree
+            int dt = -1;
+            for (int j : L.in) { const int dj = j < 0 ? c->act_dt() : c->layers[j].store_dt; if (dt >= 0 && dj != dt && (L.type == L_ROUTE || L.type == L_SHORTCUT)) return fail(c, YOLO_ERR_INVALID, "layer %d: operands stored in different types (yolo_store): a %s needs one type", i, L.type == L_ROUTE ? "route" : "shortcut"); if (dt < 0) dt = dj; }
+            L.store_dt = dt >= 0 ? dt : c->act_dt();
+        }
     }
     if (c->rows == 0) return fail(c, YOLO_ERR_INVALID, "cfg has no [yolo] / [region] / [detection] head");
     c->in_mul = (float)atof(opt_s(net, "yolo_input_mul", "1").c_str()); c->in_add = (float)atof(opt_s(net, "yolo_input_add", "0").c_str());
@@ -334,7 +353,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         Layer &L = c->layers[i];
         if (L.type == L_SHORTCUT && !c->keep_layers) {
             Layer &P = c->layers[i - 1];
-            if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1) { P.residual_from = L.in[1]; L.noop = true; }
+            if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1 && (L.in[1] < 0 || c->layers[L.in[1]].store_dt == P.store_dt)) { P.residual_from = L.in[1]; L.noop = true; }
         }
     }
     // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
@@ -381,7 +400,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
             bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
-                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % c->gran() == 0) && (off % c->gran() == 0);
+                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % gran_of(L.store_dt) == 0) && (off % gran_of(L.store_dt) == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
             if (ok) { place_route[j] = i; place_off[j] = off; }
@@ -397,7 +416,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.type == L_ROUTE && L.in.size() >= 2) {
-            L.storage = new_storage(roundup(L.C, c->gran()), c->act_dt(), (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
         }
     }
     for (int i = 0; i < NL; ++i) {
@@ -408,7 +427,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
-        else L.storage = new_storage(roundup(L.C, c->gran()), c->act_dt(), (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
     }
     // a conv whose shortcut was fused writes the shortcut layer's tensor
     for (int i = 0; i + 1 < NL; ++i) {
@@ -608,7 +627,7 @@ int run_layer(yolo_ctx *c, int i, int n)
     case L_ROUTE:
         for (size_t k = 0; k < L.copy_inputs.size(); ++k) {
             TView src = nview(view_of(c, L.copy_inputs[k])); TView dst = nview(L.out);
-            dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * c->esize(); dst.c = src.c;
+            dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * dt_size(dst.dt); dst.c = src.c;
             if (src.c % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of %d channels", src.c);
             HIPCK(c, launch_copy(src, dst, s));
         }
@@ -795,8 +814,8 @@ void resolve_scales(yolo_ctx *c)
     for (int i = 0; i < NL; ++i) {
         const Layer &L = c->layers[i];
         switch (L.type) {
-        case L_CONV: c->eff_scale[i] = (L.residual_from >= -1 && i + 1 < NL) ? c->user_scale[i + 1] : c->user_scale[i]; break;
-        case L_SHORTCUT: c->eff_scale[i] = c->user_scale[i]; break;
+        case L_CONV: c->eff_scale[i] = L.store_dt != DT_FP8 ? 1.f : (L.residual_from >= -1 && i + 1 < NL) ? c->user_scale[i + 1] : c->user_scale[i]; break;
+        case L_SHORTCUT: c->eff_scale[i] = L.store_dt != DT_FP8 ? 1.f : c->user_scale[i]; break;
         case L_ROUTE: c->eff_scale[i] = L.in.size() == 1 ? c->eff_scale[L.in[0]] : NAN; break;
         case L_UPSAMPLE: case L_MAXPOOL: case L_REORG: c->eff_scale[i] = c->eff_scale[L.in[0]]; break;
         default: break;
@@ -884,10 +903,10 @@ int yolo_set_act_scales(yolo_ctx *c, const float *scales, int n)
 // the device, so both ways of loading parameters (weight stream, export artifact) share it.
 static int tail_fragments(yolo_ctx *c)
 {
-    if (!c->half_like()) return YOLO_OK;
     std::vector<uint16_t> src, dst;
     for (auto &T : c->layers) {
         if (T.type != L_CONV || T.fused_into < 0) continue;
+        if (T.in_dt != DT_BF16 && T.in_dt != DT_F16) continue;          // (16-bit tails only; also the bf16 islands of a mixed e4m3 plan)
         const int C2 = T.filters, K = T.kpad;                        // K == the producer's channel count, a multiple of 32
         if (C2 % 16 || K % 32) continue;
         src.resize((size_t)T.cout_pad * K); dst.resize((size_t)C2 * K);

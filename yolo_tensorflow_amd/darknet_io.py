@@ -34,6 +34,102 @@ def with_input_size(text, size):
     return "\n".join(out)
 
 
+def with_layer_store(text, layers, store="bf16"):
+    """cfg text with `yolo_store=<store>` added to the [convolutional] sections whose layer index (0-based, [net] not counted) is in
+    `layers`: in an fp8 network those layers' outputs -- and what is derived from them without arithmetic (shortcut, route, upsample,
+    pooling) -- are stored in bf16, and the convs that read them run on the bf16 MFMA (mixed-precision plans).  Operands of a shortcut
+    or of a concatenating route must end up in one type; `store_closure` adds what that takes."""
+    want = set(int(l) for l in layers)
+    out, idx = [], -2
+    for line in text.splitlines():
+        t = line.strip()
+        if t.startswith("["):
+            idx += 1
+            out.append(line)
+            if idx in want:
+                if t[1:t.index("]")].strip() != "convolutional":
+                    raise ValueError("layer %d is not a [convolutional] section" % idx)
+                out.append("yolo_store=%s" % store)
+            continue
+        if t.split("=")[0].strip() == "yolo_store":
+            continue
+        out.append(line)
+    return "\n".join(out) + "\n"
+
+
+def store_closure(secs, layers):
+    """Smallest superset of the conv layers `layers` whose bf16 storage is consistent: both operands of every shortcut and all inputs
+    of every concatenating route are stored in one type (the residual stream of a stage is all-or-nothing)."""
+    L = secs[1:]
+    S = set(int(l) for l in layers)
+
+    def inputs(i):
+        s = L[i]; t = s["type"]
+        if t == "shortcut":
+            f = int(s["from"]); return [i - 1, f if f >= 0 else i + f]
+        if t == "route":
+            return [int(x) if int(x) >= 0 else i + int(x) for x in s["layers"].split(",")]
+        return [i - 1]
+
+    def is16(i, S):
+        t = L[i]["type"]
+        if t == "convolutional":
+            return i in S
+        if t in ("yolo", "region", "detection"):
+            return False
+        return any(is16(j, S) for j in inputs(i))
+
+    def force(i, S):                      # make layer i's tensor bf16
+        t = L[i]["type"]
+        if t == "convolutional":
+            S.add(i)
+        else:
+            for j in inputs(i):
+                force(j, S)
+
+    changed = True
+    while changed:
+        changed = False
+        for i, s in enumerate(L):
+            if s["type"] == "shortcut" or (s["type"] == "route" and "," in s["layers"]):
+                ins = inputs(i)
+                flags = [is16(j, S) for j in ins]
+                if any(flags) and not all(flags):
+                    before = len(S)
+                    for j in ins:
+                        force(j, S)
+                    changed = changed or len(S) != before
+    return sorted(S)
+
+
+def bf16_flop_share(secs):
+    """Share of the conv FLOPs (2 k k Cin Cout Ho Wo) of a mixed plan that runs on the bf16 MFMA: the convs whose INPUT tensor is stored
+    in bf16 (cfg key yolo_store on the producers, inherited through shortcut / route / upsample / pooling) and the first conv."""
+    L = secs[1:]
+    shapes = layer_shapes(secs)
+
+    def is16(i):
+        t = L[i]["type"]
+        if t == "convolutional":
+            return L[i].get("yolo_store") == "bf16"
+        if t in ("yolo", "region", "detection"):
+            return False
+        if t == "route":
+            ls = [int(v) if int(v) >= 0 else i + int(v) for v in L[i]["layers"].split(",")]
+            return is16(ls[0])
+        return is16(i - 1)
+
+    tot = b16 = 0.0
+    for i, s in enumerate(L):
+        if s["type"] != "convolutional":
+            continue
+        f = 2.0 * int(s["size"]) ** 2 * shapes[i][4] * shapes[i][3] * shapes[i][1] * shapes[i][2]
+        tot += f
+        if i == 0 or is16(i - 1):
+            b16 += f
+    return b16 / tot
+
+
 def parse_cfg(text):
     secs = []
     for line in text.splitlines():
