@@ -17,7 +17,7 @@ def last_json(path):
     return json.loads(line) if line else None
 
 
-for name in ("bench.json", "bench_fp8.json", "bench_under_rocprof.json"):
+for name in ("bench.json", "bench_fp8.json", "bench_mixed.json", "bench_fp16.json", "bench_fp32.json", "bench_under_rocprof.json"):
     j = last_json(os.path.join(src, name))
     if j:
         json.dump(j, open(os.path.join(dst, "%s_%s" % (R, name)), "w"), indent=1)
