@@ -223,6 +223,9 @@ def conv_layers(secs):
         elif s["type"] == "connected":       # parameters are stored like a bias conv's: biases, then weights [output][inputs]
             out.append(dict(idx=i, filters=int(s["output"]), size=1, stride=1, bn=0,
                             act=s.get("activation", "logistic"), cin=shp["cin"]))
+        elif s["type"] == "local":           # DN/parser.c:1315-1320: biases [filters][out_h][out_w], then weights [location][filter][c][kh][kw]
+            out.append(dict(idx=i, filters=int(s["filters"]), size=int(s["size"]), stride=int(s.get("stride", 1)), bn=0,
+                            act=s.get("activation", "logistic"), cin=shp["cin"], local=True, locations=shp["H"] * shp["W"]))
     return out
 
 
@@ -253,6 +256,9 @@ def _walk_shapes(secs):
         elif t == "connected":               # DN/connected_layer.c:151 / slim.flatten + fully_connected (V1/YOLO_V1_Inference.py:198-206)
             cin = H * W * C
             H, W, C = 1, 1, int(s["output"])
+        elif t == "local":                   # DN/local_layer.c:10-24: `pad` is a flag here (and the im2col pad amount, DN/local_layer.c:103)
+            k, st, pad = int(s["size"]), int(s.get("stride", 1)), int(s.get("pad", 0))
+            H, W, C = ((H - 1) if pad else (H - k)) // st + 1, ((W - 1) if pad else (W - k)) // st + 1, int(s["filters"])
         elif t in ("shortcut", "dropout"):
             pass
         elif t in ("yolo", "region", "detection"):
@@ -284,6 +290,13 @@ def unflatten_weights(flat, secs):
     for c in conv_layers(secs):
         n, k, cin = c["filters"], c["size"], c["cin"]
         p = {}
+        if c.get("local"):
+            loc = c["locations"]
+            p["bias_fl"] = flat[ptr:ptr + n * loc].reshape(n, loc).copy(); ptr += n * loc            # [filter][location]
+            cnt = loc * n * cin * k * k
+            p["w_local"] = flat[ptr:ptr + cnt].reshape(loc, n, cin, k, k).copy(); ptr += cnt         # [location][filter][c][kh][kw]
+            out.append(p)
+            continue
         if c["bn"]:
             # file order: biases(beta), scales(gamma), rolling_mean, rolling_variance
             for name in ("beta", "gamma", "mean", "var"):
@@ -752,6 +765,9 @@ def flatten_weights(params, secs):
     """Inverse of unflatten_weights: the per-conv dicts back into darknet's flat stream (file order, filters OIHW)."""
     parts = []
     for c, p in zip(conv_layers(secs), params):
+        if c.get("local"):
+            parts += [p["bias_fl"], p["w_local"]]
+            continue
         if c["bn"]:
             parts += [p["beta"], p["gamma"], p["mean"], p["var"]]
         else:
@@ -835,6 +851,28 @@ def forward(secs, params, x, semantics="tf", bn_mode="tf", emulate_bf16=False, c
                 raise ValueError(act)
             y = y.reshape(x.shape[0], 1, 1, -1)
             x = y if is_head else q(y)
+        elif t == "local":
+            # DN/local_layer.c:91-120: out[f][loc] = bias[f][loc] + sum_k W[loc][f][k] * col[k][loc], k = (c, kh, kw); then the activation
+            p = params[ci]; ci += 1
+            k, st, pad = int(s["size"]), int(s.get("stride", 1)), int(s.get("pad", 0))
+            wl = to_bf16(p["w_local"]) if emulate_bf16 else p["w_local"]
+            if emulate_bf16:
+                wl = q(p["w_local"])
+            N_, H_, W_, C_ = x.shape
+            Ho = ((H_ - 1) if pad else (H_ - k)) // st + 1; Wo = ((W_ - 1) if pad else (W_ - k)) // st + 1
+            xp = np.pad(x, ((0, 0), (pad, pad + k), (pad, pad + k), (0, 0)))
+            y = np.zeros((N_, Ho, Wo, wl.shape[1]), np.float32)
+            for oy in range(Ho):
+                for ox in range(Wo):
+                    patch = xp[:, oy * st:oy * st + k, ox * st:ox * st + k, :]                              # [N, kh, kw, c]
+                    wloc = np.transpose(wl[oy * Wo + ox], (0, 2, 3, 1))                                       # [f, kh, kw, c]
+                    y[:, oy, ox, :] = np.einsum("nhwc,fhwc->nf", patch, wloc, dtype=np.float32) + p["bias_fl"][:, oy * Wo + ox]
+            act = s.get("activation", "logistic")
+            if act == "leaky":
+                y = leaky_relu(y)
+            elif act != "linear":
+                raise ValueError(act)
+            x = q(y.astype(np.float32))
         elif t == "dropout":
             pass                                                          # inference: identity (is_training=False, :203-204)
         elif t == "detection":

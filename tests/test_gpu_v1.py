@@ -147,3 +147,34 @@ def test_yolov1_tiny_network_and_entry_point(hiplib, tmp_path):
         assert name == IO.v1_classes()[int(c)] and abs(s - sc) < 2e-3
         np.testing.assert_allclose([bx, by, bw, bh], b * np.float32(448), rtol=2e-3, atol=0.5)
 
+
+
+def test_local_layers_match_compiled_reference(hiplib, tmp_path):
+    """[local] on the device (k_local: one wave per location and filter, filters streamed once) in a topology with two of them, against
+    every layer output of the reference's own C code (tests/golden/mini_local.npz): fp32 to 2e-4, bf16 / fp16 storage to their
+    precision; batches (the reference's layer loops images over the same filters); the export artifact carries the layer."""
+    g = golden("mini_local.npz")
+    cfg = str(g["cfg"])
+    x = g["image_u8"][None]
+    secs = IO.parse_cfg(cfg)
+    for dtype, tol in ((hiplib.FP32, 2e-4), (hiplib.FP16, 4e-3), (hiplib.BF16, 3e-2)):
+        eng = hiplib.Engine(cfg, max_batch=3, dtype=dtype, semantics=hiplib.SEM_DARKNET, keep_layers=True)
+        eng.set_weights(g["weights"])
+        det = eng.forward(x)[0]
+        for i, s in enumerate(secs[1:]):
+            if s["type"] == "detection":
+                continue
+            assert _relmax(eng.layer_output(i, 1).reshape(-1), g["layer_%02d" % i].reshape(-1)) < tol, "layer %d (%s) dtype %d" % (i, s["type"], dtype)
+        np.testing.assert_allclose(det[:, 4], g["obj_raw"], rtol=tol * 10, atol=tol)
+        if dtype == hiplib.FP32:
+            three = np.concatenate([x, x[:, ::-1], x])                     # image 0 and 2 equal, image 1 different
+            d3 = eng.forward(three)
+            assert np.array_equal(d3[0], det) and np.array_equal(d3[2], det) and not np.array_equal(d3[1], det)
+            path = str(tmp_path / "local.yolohip")
+            eng.export(path)
+            e2 = hiplib.Engine.from_file(path, max_batch=1)
+            assert np.array_equal(e2.forward(x)[0], det)
+            e2.close()
+        eng.close()
+    with pytest.raises(hiplib.YoloError, match="fp8"):
+        hiplib.Engine(cfg, dtype=hiplib.FP8)

@@ -128,3 +128,30 @@ def test_darknet_veneer_exports_everything_darknet_py_binds():
     if os.path.exists(ref):                       # build container only: the list above is what that file binds
         bound = set(re.findall(r"\blib\.(\w+)", open(ref).read()))
         assert bound == set(DARKNET_PY_SYMBOLS), bound ^ set(DARKNET_PY_SYMBOLS)
+
+
+def test_draw_detection_counterpart(tmp_path):
+    """yolo_tensorflow_amd/draw.py vs the reference's draw_detection rules (V2/utils.py:65-94, D2T/...V3...py:547-582): colour table
+    (HSV wheel shuffled with seed 10101 -- restated here with the same stdlib calls), threshold, ratio -> pixel truncation, thickness,
+    label text and placement; the rendered picture carries the class colour on the box outline and leaves the input untouched."""
+    import colorsys, random
+    from yolo_tensorflow_amd import draw
+    labels = ["a%d" % i for i in range(20)]
+    hsv = [(x / 20.0, 1., 1.) for x in range(20)]
+    want = [tuple(int(v * 255) for v in colorsys.hsv_to_rgb(*c)) for c in hsv]
+    random.seed(10101); random.shuffle(want); random.seed(None)
+    assert draw.class_colors(20) == want
+    im = np.full((300, 600, 3), 30, np.uint8)
+    boxes = np.array([[0.1, 0.01, 0.5, 0.5], [0.6, 0.4, 0.9, 0.9], [0.2, 0.2, 0.3, 0.3]], np.float32)
+    scores = np.array([0.9, 0.5, 0.1], np.float32); cls = np.array([3, 7, 1])
+    ov = draw.detection_overlays(im.shape, boxes, scores, cls, labels, thr=0.3, ratio=True)
+    assert len(ov) == 2                                              # the 0.1 one is below the threshold
+    # (float32 0.01 * 300.0 in double = 2.99999993 -> int 2: the reference's `int(bboxes[i][1] * (1.0 * h))` truncates the same way)
+    assert ov[0][0] == (60, 2, 300, 150) and ov[0][1] == want[3] and ov[0][2] == int(900 / 300) // 3
+    assert ov[0][3] == "a3: 0.900" and ov[0][4] == (62, 17)          # box touches the top: label goes inside
+    assert ov[1][0] == (360, 120, 540, 270) and ov[1][4] == (360, 110)
+    px = draw.detection_overlays(im.shape, [[60, 30, 300, 150]], [0.8], [2], labels)          # pixel boxes (V2 flavour): full thickness
+    assert px[0][0] == (60, 30, 300, 150) and px[0][2] == 3
+    out = draw.draw_detection(im, boxes, scores, cls, labels, thr=0.3, ratio=True)
+    assert out.shape == im.shape and (im == 30).all()
+    assert tuple(out[150, 60]) == want[3] and tuple(out[120, 450]) == want[7] and tuple(out[200, 100]) == (30, 30, 30)

@@ -133,3 +133,22 @@ def test_v1_restatement_matches_compiled_reference():
     full = R.v1_rows(heads[0][1][0], 3, 2, 20)
     smax = (full[:, 4:5] * full[:, 5:]).max(-1)
     assert len(s) > 0 and (np.diff(s) <= 0).all() and set(np.round(s, 6)).issubset(set(np.round(smax[smax >= 0.2], 6)))
+
+
+def test_local_layer_restatement_matches_compiled_reference():
+    """[local] (locally connected, DN/local_layer.c:91-120; darknet's own yolov1.cfg): the oracle's restatement -- biases [filter][location],
+    weights [location][filter][c][kh][kw], `pad` as flag and im2col amount -- against every layer output of the reference's C code on a
+    topology with a same-size 3x3 / pad 1 and a 2x2 / stride 2 / unpadded local layer (tests/golden/mini_local.npz, gen_mini_local)."""
+    g = golden("mini_local.npz")
+    cfg = str(g["cfg"])
+    secs = R.parse_cfg(cfg); params = R.unflatten_weights(g["weights"], secs)
+    assert [s["type"] for s in secs[1:]].count("local") == 2
+    np.testing.assert_array_equal(R.flatten_weights(params, secs), g["weights"])                 # the [local] parameter layout round-trips
+    x = g["image_u8"].astype(np.float32) / np.float32(255)
+    heads, outs = R.forward(secs, params, x[None], semantics="darknet", bn_mode="darknet", collect=True)
+    for i, o in enumerate(outs):
+        if o is not None:
+            ref = g["layer_%02d" % i].reshape(o.shape)
+            assert np.abs(o - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), "layer %d" % i
+    rows = R.v1_rows(heads[0][1][0], 3, 2, 2)
+    np.testing.assert_allclose(rows[:, 4], g["obj_raw"], rtol=1e-5, atol=1e-6)

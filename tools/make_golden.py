@@ -412,6 +412,32 @@ def gen_mini_v1():
     net.close()
 
 
+MINI_LOCAL = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mini_local.cfg")).read()
+
+
+def gen_mini_local():
+    """[local] layers (locally connected: unshared filters per output location, DN/local_layer.c:91-120; darknet's own yolov1.cfg has one
+    between its last conv and the fully connected head): a same-size 3x3 / pad 1 one and a 2x2 / stride 2 / unpadded one, then
+    [connected] + [detection], through the compiled reference.  (The first conv is there for its workspace: the reference sizes a
+    [local] layer's im2col workspace in elements, not bytes -- DN/local_layer.c:64 -- and relies on an earlier conv's being larger.)"""
+    from oracle import darknet_ref as D
+    from yolo_tensorflow_amd import darknet_io as IO
+    secs = IO.parse_cfg(MINI_LOCAL)
+    flat = IO.synth_weights(secs, seed=2)
+    net = D.RefNet(MINI_LOCAL, flat, 0, 1)
+    img = np.random.default_rng(17).integers(0, 256, (48, 48, 3), dtype=np.uint8)
+    net.predict(img.astype(np.float32) / np.float32(255.0))
+    data = {"cfg": np.array(MINI_LOCAL), "weights": flat, "image_u8": img, "header": np.array([0, 1])}
+    for i in range(net.n):
+        data["layer_%02d" % i] = net.layer_output_nhwc(i).astype(np.float32)
+    bb, obj, pr = net.boxes(0.2, None, 2)
+    data["boxes_raw"], data["obj_raw"], data["prob_raw"] = bb, obj, pr
+    data["thresh"] = np.float32(0.2)
+    np.savez_compressed(os.path.join(OUT, "mini_local.npz"), **data)
+    print("mini_local layers", net.n, "boxes", len(bb))
+    net.close()
+
+
 def gen_mini(name, cfg, classes, nms_thresh=0.3, thresh=0.15):
     from oracle import darknet_ref as D
     from yolo_tensorflow_amd import darknet_io as IO
@@ -445,3 +471,4 @@ if __name__ == "__main__":
     gen_mini("mini_v3", MINI_V3, 4)
     gen_mini("mini_v2", MINI_V2, 5)
     gen_mini_v1()
+    gen_mini_local()

@@ -449,3 +449,50 @@ hipError_t launch_letterbox_planar(const float *img, int iw, int ih, int w, int 
     hipLaunchKernelGGL(k_letterbox_planar, grid_for((size_t)w * h), dim3(256), 0, s, img, iw, ih, w, h, new_w, new_h, (w - new_w) / 2, (h - new_h) / 2, out);
     return hipGetLastError();
 }
+
+// ---- [local]: locally connected layer (DN/local_layer.c:91-120): a conv whose filters are NOT shared between output locations.
+//      out[n, oy, ox, f] = act(bias[loc][f] + sum_{kh,kw,c} W[loc][f][kh][kw][c] * in[n, oy s - p + kh, ox s - p + kw, c]), loc = oy Wo + ox.
+//      Every filter value is used once per image: the layer streams its weights (darknet's yolov1.cfg: 49 locations x 256 x 9216) and
+//      is HBM-bound by construction.  One wave per (location, filter): lanes run along the 8-channel granules of a tap (16-byte loads
+//      of filter and activation), fp32 accumulation, shuffle reduction; the image loop is inside so the filter row is read once. ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_local(const T *in, int in_stride, const T *w, const float *bias, T *out, int out_stride,
+                                               int n, int H, int W, int C, int Ho, int Wo, int F, int k, int stride, int pad, int act)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int loc = blockIdx.x, f = blockIdx.y * 4 + wv;
+    if (f >= F) return;
+    const int oy = loc / Wo, ox = loc - oy * Wo;
+    const int c8n = C / 8, K8 = k * k * c8n;                      // 8-channel granules per tap / per filter row
+    const T *wr = w + ((size_t)loc * F + f) * (size_t)K8 * 8;
+    for (int b = 0; b < n; ++b) {
+        float acc = 0.f;
+        for (int g = lane; g < K8; g += 64) {
+            const int t = g / c8n, c8 = g - t * c8n;
+            const int kh = t / k, kw = t - kh * k;
+            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            float xv[8], wv8[8];
+            Elt<T>::load8(in + ((size_t)(b * H + iy) * W + ix) * in_stride + c8 * 8, xv);
+            Elt<T>::load8(wr + (size_t)g * 8, wv8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fmaf(xv[q], wv8[q], acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) {
+            float v = acc + bias[(size_t)loc * F + f];
+            if (act == ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+            Elt<T>::store1(out + ((size_t)b * Ho * Wo + loc) * out_stride + f, v);
+        }
+    }
+}
+
+hipError_t launch_local(const TView &in, const TView &out, const void *w, const float *bias, int k, int stride, int pad, int act, hipStream_t s)
+{
+    if (in.c % 8 || in.dt != out.dt || in.dt == DT_FP8) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(out.h * out.w), (unsigned)((out.c + 3) / 4));
+    WITH_DT(in.dt, hipLaunchKernelGGL(k_local<T>, grid, dim3(256), 0, s, (const T *)in.ptr, in.stride, (const T *)w, bias, (T *)out.ptr, out.stride,
+                                      in.n, in.h, in.w, in.c, out.h, out.w, out.c, k, stride, pad, act));
+    return hipGetLastError();
+}

@@ -144,6 +144,8 @@ hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darkn
 // out = (a * sa + b * sb) * so   (the scales are the fp8 tensor scales; 1 for bf16 / fp32)
 hipError_t launch_add(const TView &a, const TView &b, const TView &out, hipStream_t s, float sa = 1.f, float sb = 1.f, float so = 1.f);
 hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s);
+// [local] (locally connected, DN/local_layer.c): w [locations][filters][k][k][C] in the tensors' type, bias [locations][filters] fp32
+hipError_t launch_local(const TView &in, const TView &out, const void *w, const float *bias, int k, int stride, int pad, int act, hipStream_t s);
 hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s, float scale = 1.f);   // dense NHWC fp32 copy (* scale)
 hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, float scale = 1.f);   // (in * scale) -> view
 

@@ -24,7 +24,7 @@
 
 namespace {
 
-enum LType { L_CONV, L_SHORTCUT, L_ROUTE, L_UPSAMPLE, L_MAXPOOL, L_REORG, L_YOLO, L_REGION, L_DETECT };
+enum LType { L_CONV, L_SHORTCUT, L_ROUTE, L_UPSAMPLE, L_MAXPOOL, L_REORG, L_YOLO, L_REGION, L_DETECT, L_LOCAL };
 
 struct Section { std::string type; std::map<std::string, std::string> kv; };
 
@@ -272,6 +272,21 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             c->conv_flops += 2.0 * L.cin * L.filters;
             c->weights_count += (size_t)L.filters + (size_t)L.filters * L.cin;
             H = 1; W = 1; C = L.filters;
+        } else if (s.type == "local") {
+            // locally connected (DN/local_layer.c; darknet's own yolov1.cfg): `pad` is a flag AND the im2col pad amount (:10-24, :103)
+            if (c->dtype == YOLO_FP8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] is not served in the fp8 configuration", i);
+            L.type = L_LOCAL; L.filters = opt_i(s, "filters", 1); L.size = opt_i(s, "size", 1); L.stride = opt_i(s, "stride", 1); L.pad = opt_i(s, "pad", 0);
+            if (L.pad != 0 && L.pad != 1) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] pad must be 0 or 1", i);
+            std::string act = opt_s(s, "activation", "logistic");
+            if (act == "leaky") L.act = ACT_LEAKY; else if (act == "linear") L.act = ACT_LINEAR;
+            else return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: activation '%s' unsupported", i, act.c_str());
+            if (C % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] needs a producer with a multiple of 8 channels", i);
+            L.cin = C; L.cin_pad = C; L.in_dt = c->act_dt(); L.store_dt = c->act_dt();
+            const int ho = ((L.pad ? H - 1 : H - L.size)) / L.stride + 1, wo = ((L.pad ? W - 1 : W - L.size)) / L.stride + 1;
+            if (ho < 1 || wo < 1) return fail(c, YOLO_ERR_INVALID, "layer %d: [local] larger than its input", i);
+            H = ho; W = wo; C = L.filters;
+            c->conv_flops += 2.0 * L.size * L.size * L.cin * L.filters * (double)H * W;
+            c->weights_count += (size_t)L.filters * H * W + (size_t)H * W * L.filters * L.cin * L.size * L.size;
         } else if (s.type == "dropout") {
             L.type = L_ROUTE;                       // inference: identity (DN/dropout_layer.c:38-40)
         } else if (s.type == "detection") {
@@ -335,7 +350,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: section [%s] is outside the inference hot path", i, s.type.c_str());
         }
         L.H = H; L.W = W; L.C = C;
-        if (L.type != L_CONV) {
+        if (L.type != L_CONV && L.type != L_LOCAL) {
             // layers that move data keep the type of what they move; their operands must agree
             int dt = -1;
             for (int j : L.in) { const int dj = j < 0 ? c->act_dt() : c->layers[j].store_dt; if (dt >= 0 && dj != dt && (L.type == L_ROUTE || L.type == L_SHORTCUT)) return fail(c, YOLO_ERR_INVALID, "layer %d: operands stored in different types (yolo_store): a %s needs one type", i, L.type == L_ROUTE ? "route" : "shortcut"); if (dt < 0) dt = dj; }
@@ -530,6 +545,10 @@ int allocate(yolo_ctx *c)
         HIPCK(c, hipMalloc((void **)&L.d_b, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_b, 0, (size_t)L.cout_pad * 4, c->stream));
         if (L.in_dt == DT_FP8) { HIPCK(c, hipMalloc((void **)&L.d_sc, (size_t)L.cout_pad * 4)); HIPCK(c, hipMemsetAsync(L.d_sc, 0, (size_t)L.cout_pad * 4, c->stream)); }
     }
+    for (auto &L : c->layers) if (L.type == L_LOCAL) {
+        const size_t wn = (size_t)L.H * L.W * L.filters * L.size * L.size * L.cin;
+        HIPCK(c, hipMalloc(&L.d_w, wn * dt_size(L.in_dt))); HIPCK(c, hipMalloc((void **)&L.d_b, (size_t)L.H * L.W * L.filters * 4));
+    }
     if (c->dtype != YOLO_FP32)
         for (size_t i = 1; i < c->layers.size(); ++i) {
             const Layer &Y = c->layers[i]; Layer &P = c->layers[i - 1];
@@ -632,6 +651,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             HIPCK(c, launch_copy(src, dst, s));
         }
         break;
+    case L_LOCAL: HIPCK(c, launch_local(nview(view_of(c, L.in[0])), nview(L.out), L.d_w, L.d_b, L.size, L.stride, L.pad, L.act, s)); break;
     case L_UPSAMPLE: HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
     case L_MAXPOOL: HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
     case L_REORG: HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
@@ -932,6 +952,28 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
     std::vector<uint8_t> wbuf; std::vector<float> bias, osc;
     resolve_scales(c);
     for (auto &L : c->layers) {
+        if (L.type == L_LOCAL) {
+            // file: biases [filter][location], weights [location][filter][c][kh][kw] (DN/parser.c:1315-1320) -> device: bias [location][filter],
+            // weights [location][filter][kh][kw][c] in the activations' type
+            const int loc = L.H * L.W, F = L.filters, k = L.size, C = L.cin;
+            const float *bfile = p; p += (size_t)F * loc;
+            const float *wfile = p; p += (size_t)loc * F * C * k * k;
+            std::vector<float> b((size_t)loc * F);
+            for (int f = 0; f < F; ++f) for (int l = 0; l < loc; ++l) b[(size_t)l * F + f] = bfile[(size_t)f * loc + l];
+            const size_t es = dt_size(L.in_dt);
+            std::vector<uint8_t> wb((size_t)loc * F * k * k * C * es);
+            for (size_t lf = 0; lf < (size_t)loc * F; ++lf)
+                for (int ch = 0; ch < C; ++ch)
+                    for (int t = 0; t < k * k; ++t) {
+                        const float v = wfile[(lf * C + ch) * k * k + t];
+                        const size_t idx = (lf * k * k + t) * C + ch;
+                        if (L.in_dt == DT_F32) memcpy(&wb[idx * 4], &v, 4);
+                        else { uint16_t h = L.in_dt == DT_F16 ? f2h(v) : f2bf(v); memcpy(&wb[idx * 2], &h, 2); }
+                    }
+            HIPCK(c, hipMemcpy(L.d_w, wb.data(), wb.size(), hipMemcpyHostToDevice));
+            HIPCK(c, hipMemcpy(L.d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+            continue;
+        }
         if (L.type != L_CONV) continue;
         const float *params = p; p += (size_t)L.filters * (L.bn ? 4 : 1);
         const float *w = p; p += (size_t)L.filters * L.cin * L.size * L.size;
@@ -1026,8 +1068,9 @@ int yolo_export(yolo_ctx *c, const char *path)
     std::vector<int32_t> plan(NL); yolo_get_tile_configs(c, plan.data()); w.put(plan.data(), NL * 4);
     std::vector<uint8_t> buf;
     for (auto &L : c->layers) {
-        if (L.type != L_CONV) continue;
-        const uint64_t sz[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        if (L.type != L_CONV && L.type != L_LOCAL) continue;
+        uint64_t sz[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        if (L.type == L_LOCAL) { sz[0] = (uint64_t)L.H * L.W * L.filters * L.size * L.size * L.cin * dt_size(L.in_dt); sz[1] = (uint64_t)L.H * L.W * L.filters; sz[2] = 0; }
         w.put(sz, sizeof sz);
         const void *src[3] = {L.d_w, L.d_b, L.d_sc}; const size_t bytes[3] = {(size_t)sz[0], (size_t)sz[1] * 4, (size_t)sz[2] * 4};
         for (int k = 0; k < 3; ++k) {
@@ -1064,9 +1107,10 @@ yolo_ctx *yolo_create_from_file(const char *path, int max_batch, int device, voi
     if (c->dtype == YOLO_FP8 && yolo_set_act_scales(c, sc.data(), (int)hd.n_layers) != YOLO_OK) { fclose(f); return bail(c, c->err); }
     std::vector<uint8_t> buf;
     for (auto &L : c->layers) {
-        if (L.type != L_CONV) continue;
+        if (L.type != L_CONV && L.type != L_LOCAL) continue;
         uint64_t sz[3]; r.get(sz, sizeof sz);
-        const uint64_t want[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        uint64_t want[3] = {(uint64_t)L.cout_pad * L.kpad * dt_size(L.in_dt), (uint64_t)L.cout_pad, L.d_sc ? (uint64_t)L.cout_pad : 0};
+        if (L.type == L_LOCAL) { want[0] = (uint64_t)L.H * L.W * L.filters * L.size * L.size * L.cin * dt_size(L.in_dt); want[1] = (uint64_t)L.H * L.W * L.filters; want[2] = 0; }
         if (!r.ok || sz[0] != want[0] || sz[1] != want[1] || sz[2] != want[2]) { fclose(f); return bail(c, "artifact parameters do not fit the topology (truncated file or different packing)"); }
         void *dst[3] = {L.d_w, L.d_b, L.d_sc}; const size_t bytes[3] = {(size_t)sz[0], (size_t)sz[1] * 4, (size_t)sz[2] * 4};
         for (int k = 0; k < 3; ++k) {

@@ -171,6 +171,9 @@ def layer_shapes(secs):
         elif t == "connected":               # flattens its producer (CHW order, DN/connected_layer.c:151) to `output` values
             cin = H * W * C
             H, W, C = 1, 1, int(s["output"])
+        elif t == "local":                   # locally connected: unshared filters per output location (DN/local_layer.c:10-24)
+            k, st, pad = int(s["size"]), int(s.get("stride", 1)), int(s.get("pad", 0))
+            H, W, C = ((H - 1) if pad else (H - k)) // st + 1, ((W - 1) if pad else (W - k)) // st + 1, int(s["filters"])
         elif t == "detection":
             H = W = int(s.get("side", 7))
         elif t not in ("shortcut", "yolo", "region", "dropout"):
@@ -192,13 +195,16 @@ def conv_specs(secs):
                             bn=int(s.get("batch_normalize", 0)), head=head, index=i))
         elif s["type"] == "connected":
             out.append(dict(filters=int(s["output"]), size=1, cin=shapes[i][4], bn=0, head=head, index=i))
+        elif s["type"] == "local":           # biases [filters * locations], weights [locations][filters][cin][k][k] (DN/parser.c:1315-1320)
+            out.append(dict(filters=int(s["filters"]), size=int(s["size"]), cin=shapes[i][4], bn=0, head=False, index=i, locations=shapes[i][1] * shapes[i][2]))
     return out
 
 
 def weights_count(secs):
     n = 0
     for c in conv_specs(secs):
-        n += c["filters"] * (4 if c["bn"] else 1) + c["filters"] * c["cin"] * c["size"] ** 2
+        loc = c.get("locations", 1)
+        n += c["filters"] * loc * (4 if c["bn"] else 1) + loc * c["filters"] * c["cin"] * c["size"] ** 2
     return n
 
 
@@ -270,6 +276,11 @@ def synth_weights(secs, seed=0, obj_bias=-0.75, stats="benign"):
                 parts.append(b)
                 parts.append(rng.normal(0, np.sqrt(1.0 / (k * k * cin * max(cur, 1e-6))), n * cin * k * k))
                 cur = 1.0 + 1.0
+        elif t == "local":
+            n, k, cin = int(s["filters"]), int(s["size"]), shapes[i][4]
+            loc = shapes[i][1] * shapes[i][2]
+            parts += [rng.normal(0, .1, n * loc), rng.normal(0, np.sqrt(2.0 / (k * k * cin * max(cur, 1e-6))), loc * n * cin * k * k)]
+            cur = 1.01 * (0.505 if s.get("activation", "linear") == "leaky" else 1.0)
         elif t == "connected":
             n, cin = int(s["output"]), shapes[i][4]
             if i + 1 < len(layers) and layers[i + 1]["type"] == "detection":

@@ -62,7 +62,7 @@ class _Detector:
 
     def detect_from_file(self, image_file, imshow=False, deteted_boxes_file="boxes.txt", detected_image_file=None):
         """(sic: `deteted_boxes_file` is the reference's spelling.)  Reads the image with PIL instead of OpenCV and
-        returns the predictions; drawing/imshow are outside the hot path."""
+        returns the predictions; with `detected_image_file` the boxes are drawn (draw.draw_detection) and the picture is saved."""
         from PIL import Image
         img = np.asarray(Image.open(image_file).convert("RGB"))
         scores, boxes, classes = self.detect_from_image(img)
@@ -72,6 +72,12 @@ class _Detector:
             with open(deteted_boxes_file, "w") as fh:
                 for p in preds:
                     fh.write(",".join(str(v) for v in p) + "\n")
+        if detected_image_file:           # the reference's draw_detection + cv2.imwrite (D2T/...V3...py:547-582, :600-612), with PIL
+            from . import draw
+            labels = self.class_names if self.class_names else {int(c): str(int(c)) for c in classes}
+            n = max(len(labels), int(max(classes, default=0)) + 1) if isinstance(labels, dict) else len(labels)
+            names = [labels.get(i, str(i)) for i in range(n)] if isinstance(labels, dict) else labels
+            Image.fromarray(draw.draw_detection(img, boxes, scores, classes, names, thr=0.3, ratio=True)).save(detected_image_file)
         return preds
 
 
