@@ -70,6 +70,10 @@ constexpr int ST_IH = ST_LH + 2, ST_IW = ST_LW + 2;          // input pixels a t
 constexpr int ST_INPIX = ST_IH * ST_IW;                      // 665
 constexpr int ST_INCHUNKS = (ST_INPIX + 63) / 64;            // 64-pixel LDS-DMA pieces: 11
 constexpr int ST_IN_BYTES = ST_INCHUNKS * 1024 + 16;         // + one 16-B slot of zeros (taps 9..11 of the K padding)
+constexpr int ST_RAW_ROW = 112;                              // U8 form: bytes of one raw input row in LDS (35 px x 3 B = 105, + up to 3 of alignment slack, as 28 dwords)
+constexpr int ST_RAW_DW = ST_IH * (ST_RAW_ROW / 4);          // 532 dwords per tile
+constexpr int ST_RAW_PIECES = (ST_RAW_DW + 63) / 64;         // 4-byte LDS-DMA pieces (256 B each): 9
+constexpr int ST_RAW_BYTES = ST_RAW_PIECES * 256;
 constexpr int ST_O2PITCH = 32 * 2 + 16;                      // staged tail tile: 32 bf16 + pad
 constexpr int ST_OUT2_BYTES = ST_TH * ST_TW * ST_O2PITCH;    // 10240
 constexpr int ST_W2PITCH = 64 * 2 + 16;                      // tail filter row pitch: 128 B rows would put all 16 lanes of a
@@ -79,7 +83,10 @@ constexpr int ST_B1_BYTES = 64 * 4;                          // layer-1 bias: re
 constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
                                                              // would make hipcc wait vmcnt(0) and drain the input prefetch
 
-template <bool H16>
+// U8: the image is read as the caller's uint8 [N, H, W, 3] itself: the raw rows of a tile are gathered by 4-byte LDS-DMA one tile ahead and
+// converted to the 16-byte pixel records (x * scale [* mul + add], rounded to the storage type: exactly k_preprocess's arithmetic) at the
+// start of their tile -- the separate conversion launch and its [N, H, W, 8] tensor (88 MB written, 88 MB read at 416 x 416 x 32) disappear.
+template <bool H16, bool U8 = false>
 __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -133,11 +140,65 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         }
     };
 
+    // (U8: the descriptor ends with the image tensor -- the 4-byte loads of a row's slack must not touch what lies behind it)
+    __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)(U8 ? (const void *)a.in_u8 : a.in), 0, U8 ? (unsigned)(((size_t)a.N * a.H * a.W * 3) & ~(size_t)3) : 0x80000000u, 0x00020000);
+    // U8: byte offset of input pixel (iy0, ix0) of `tile` (may be negative at the left / top border: those bytes are masked at conversion)
+    auto tile_origin = [&](int tile, int &n, int &iy0, int &ix0) {
+        n = tile / per_img; const int tr = tile - n * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        iy0 = 2 * ty * ST_TH - 2; ix0 = 2 * tx * ST_TW - 2;
+    };
+    auto fetch_raw = [&](int tile, char *dst) {
+        int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
+#pragma unroll
+        for (int k = 0; k < (ST_RAW_PIECES + ST_NW - 1) / ST_NW; ++k) {
+            const int c = wave + ST_NW * k;
+            if (c < ST_RAW_PIECES) {
+                const int g = c * 64 + lane;                         // dword of the tile's raw image: row g / 28, dword g % 28
+                const int r = (g * 2341) >> 16;                      // g / 28 for g < 1170
+                const int d = g - r * (ST_RAW_ROW / 4);
+                const int iy = iy0 + r;
+                const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;    // first byte the row needs
+                const bool ok = g < ST_RAW_DW && tile < ntiles && (unsigned)iy < (unsigned)a.H;
+                const unsigned off = ok ? (unsigned)((s_r & ~3) + 4 * d) : 0x80000000u;      // (a negative offset is out of range too: zeros)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (st_lds_void *)(dst + c * 256), 4, off, 0, 0, 0);
+            }
+        }
+    };
+    // raw rows of `tile` (in `raw`) -> 16-byte pixel records (3 converted channels + 5 zeros) in `pix`; pixels outside the image are zeros
+    auto convert_raw = [&](int tile, const char *__restrict__ raw, char *__restrict__ pix) {
+        int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
+#pragma unroll
+        for (int j = 0; j < (ST_INPIX + 64 * ST_NW - 1) / (64 * ST_NW); ++j) {
+            const int p = tid + j * 64 * ST_NW;
+            if (p < ST_INPIX) {
+                const int ry = (p * 1873) >> 16, rxx = p - ry * ST_IW;       // p / 35
+                const int iy = iy0 + ry, ix = ix0 + rxx;
+                const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;
+                const int b = (s_r & 3) + 3 * rxx;                           // byte of the pixel in its row's LDS slot
+                const unsigned *q = (const unsigned *)(raw + ry * ST_RAW_ROW + (b & ~3));
+                const unsigned x = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(b & 3));
+                float v0 = __fmul_rn((float)(x & 0xffu), a.in_scale), v1 = __fmul_rn((float)((x >> 8) & 0xffu), a.in_scale), v2 = __fmul_rn((float)((x >> 16) & 0xffu), a.in_scale);
+                if (a.in_mul != 1.0f || a.in_add != 0.0f) { v0 = __fadd_rn(__fmul_rn(v0, a.in_mul), a.in_add); v1 = __fadd_rn(__fmul_rn(v1, a.in_mul), a.in_add); v2 = __fadd_rn(__fmul_rn(v2, a.in_mul), a.in_add); }
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                *(uint4 *)(pix + p * 16) = ok ? uint4{stem_pk<H16>(v0, v1), stem_pk<H16>(v2, 0.f), 0u, 0u} : uint4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+
     // One tile.  Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling
     // `in_next` cannot alias the reads below, instead of waiting vmcnt(0) before the first ds_read after it.
-    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur,
-                       char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2) {
-        fetch(next_tile, in_next);                               // lands during this tile's two phases
+    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur_,
+                       char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2, char *__restrict__ pix) {
+        const char *__restrict__ in_cur = in_cur_;
+        if constexpr (U8) {
+            fetch_raw(next_tile, in_next);                       // lands during this tile
+            convert_raw(tile, in_cur_, pix);                     // (its raw rows landed during the previous tile)
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this thread's records are written
+            __builtin_amdgcn_s_barrier();
+            in_cur = pix;
+        } else
+            fetch(next_tile, in_next);                           // lands during this tile's two phases
         const int n = tile / per_img, tr = tile - n * per_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
@@ -236,8 +297,12 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         // after its own first barrier, by which time every thread has finished the reads of `lo` / `lo2` above
     };
 
-    char *const inb0 = smem, *const inb1 = smem + ST_IN_BYTES;
-    char *const l0 = smem + 2 * ST_IN_BYTES, *const lo = l0 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
+    // LDS: [input buffer 0 | input buffer 1 | layer-0 tile | staged tiles | tail filters, biases]; U8: the two input buffers hold raw rows
+    // (2304 B each) and the pixel records of the CURRENT tile follow them
+    constexpr int INB = U8 ? ST_RAW_BYTES : ST_IN_BYTES;
+    char *const inb0 = smem, *const inb1 = smem + INB;
+    char *const pixb = smem + 2 * INB;
+    char *const l0 = pixb + (U8 ? ST_IN_BYTES : 0), *const lo = l0 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
     if (a.w2)                                                    // tail filters -> LDS, 16 B per thread (256 pieces)
         if (tid < 32 * 8) {
             const int row = tid >> 3, piece = tid & 7;
@@ -245,14 +310,15 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
         }
     if (tid < 64) *(float *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + tid * 4) = a.b1[tid];
-    if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
+    if constexpr (U8) { if (tid < 4) ((uint32_t *)(pixb + ST_INCHUNKS * 1024))[tid] = 0; }           // the zero slot of the K padding
+    else if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
     int tile = blockIdx.x;
-    if (tile < ntiles) fetch(tile, inb0);
+    if (tile < ntiles) { if constexpr (U8) fetch_raw(tile, inb0); else fetch(tile, inb0); }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo, lo2, lw2);
-        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo, lo2, lw2);
+        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo, lo2, lw2, pixb);
+        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo, lo2, lw2, pixb);
     }
 #endif
 }
@@ -426,11 +492,17 @@ hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES + ST_B1_BYTES;
-    const bool h16 = a.dt == DT_F16;
-    { hipError_t e = conv_opt_in_lds(h16 ? (const void *)conv_stem_c32_c64<true> : (const void *)conv_stem_c32_c64<false>, lds); if (e != hipSuccess) return e; }
+    const bool h16 = a.dt == DT_F16, u8 = a.in_u8 != nullptr;
+    if (u8 && (double)a.N * a.H * a.W * 3 >= 2147483648.0) return hipErrorInvalidValue;
+    const void *k = h16 ? (u8 ? (const void *)conv_stem_c32_c64<true, true> : (const void *)conv_stem_c32_c64<true, false>)
+                        : (u8 ? (const void *)conv_stem_c32_c64<false, true> : (const void *)conv_stem_c32_c64<false, false>);
+    { hipError_t e = conv_opt_in_lds(k, lds + (u8 ? 2 * ST_RAW_BYTES : 0)); if (e != hipSuccess) return e; }
+    const size_t ldsb = u8 ? lds - ST_IN_BYTES + 2 * ST_RAW_BYTES : lds;
     const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
-    if (h16) hipLaunchKernelGGL(conv_stem_c32_c64<true>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
-    else hipLaunchKernelGGL(conv_stem_c32_c64<false>, dim3((unsigned)blocks), dim3(64 * ST_NW), lds, s, a);
+    if (h16 && u8) hipLaunchKernelGGL((conv_stem_c32_c64<true, true>), dim3((unsigned)blocks), dim3(64 * ST_NW), ldsb, s, a);
+    else if (h16) hipLaunchKernelGGL((conv_stem_c32_c64<true, false>), dim3((unsigned)blocks), dim3(64 * ST_NW), ldsb, s, a);
+    else if (u8) hipLaunchKernelGGL((conv_stem_c32_c64<false, true>), dim3((unsigned)blocks), dim3(64 * ST_NW), ldsb, s, a);
+    else hipLaunchKernelGGL((conv_stem_c32_c64<false, false>), dim3((unsigned)blocks), dim3(64 * ST_NW), ldsb, s, a);
     return hipGetLastError();
 }

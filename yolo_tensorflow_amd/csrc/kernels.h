@@ -107,6 +107,7 @@ hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diag
 // fused stem: conv 3x3/s1 (3 -> 32) + conv 3x3/s2 (32 -> 64), bf16 (conv_stem.hip)
 struct StemArgs {
     const void *in; int in_stride;            // [N,H,W,8] bf16 image (3 real channels)
+    const uint8_t *in_u8; float in_scale, in_mul, in_add;      // or (in_u8 != nullptr) the uint8 [N,H,W,3] image itself, converted in the kernel as k_preprocess would: x * in_scale [* in_mul + in_add]
     const void *w0; const float *b0; int Kpad0, C0, act0;    // layer 0: [C0 pad][Kpad0], k = tap*8 + ci
     const void *w1; const float *b1; int Kpad1, C1, act1;    // layer 1: [C1 pad][Kpad1], k = tap*C0 + ci
     void *out; int out_stride;                // [N,Ho,Wo,C1] bf16

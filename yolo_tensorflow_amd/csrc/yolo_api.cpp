@@ -86,6 +86,7 @@ struct yolo_ctx {
     void *d_zeros = nullptr;
     void *d_stage = nullptr; size_t stage_bytes = 0;     // host->device image staging
     TView s2d;                            // [n, S/2, S/2, 32]: space-to-depth of the input for a 7x7/2 first conv
+    const uint8_t *stem_u8 = nullptr; float stem_scale = 1.f;      // uint8 image the fused stem reads itself (no conversion launch), or nullptr: c->input
     float in_mul = 1.f, in_add = 0.f;     // input normalisation after the /255: v * in_mul + in_add ([net] yolo_input_mul / yolo_input_add)
     float *d_det = nullptr; int rows = 0, attrs = 0;
     // lean detect path (yolo_detect*): the decode writes scores, labels and the four box numbers of every row, not the tensor
@@ -602,6 +603,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             const Layer &A = c->layers[0];
             StemArgs t; memset(&t, 0, sizeof t);
             t.in = c->input.ptr; t.in_stride = c->input.stride;
+            t.in_u8 = c->stem_u8; t.in_scale = c->stem_scale; t.in_mul = c->in_mul; t.in_add = c->in_add;
             t.w0 = A.d_w; t.b0 = A.d_b; t.Kpad0 = A.kpad; t.C0 = A.filters; t.act0 = A.act;
             t.w1 = L.d_w; t.b1 = L.d_b; t.Kpad1 = L.kpad; t.C1 = L.filters; t.act1 = L.act;
             if (i + 1 < (int)c->layers.size() && c->layers[i + 1].stem_tail) {
@@ -711,6 +713,12 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     if (loc == YOLO_HOST) {
         HIPCK(c, hipMemcpyAsync(c->d_stage, images, npix * 3 * (fmt == YOLO_IMG_U8 ? 1 : 4), hipMemcpyHostToDevice, c->stream));
         src = c->d_stage;
+    }
+    // uint8 images of a network whose first layers run as the fused stem: the stem converts the pixels itself (conv_stem.hip, U8 form)
+    c->stem_u8 = nullptr;
+    if (fmt == YOLO_IMG_U8 && c->layers.size() > 1 && c->layers[1].stem && !getenv("YOLO_NO_STEM_U8") && (double)npix * 3 < 2147483648.0 && ((size_t)src & 3) == 0) {
+        c->stem_u8 = (const uint8_t *)src; c->stem_scale = scale;
+        return YOLO_OK;
     }
     HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream, c->in_mul, c->in_add));
     return YOLO_OK;
@@ -1193,6 +1201,7 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
         HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3));
         HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
     }
+    c->stem_u8 = nullptr;
     hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
@@ -1212,6 +1221,7 @@ int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h
         HIPCK(c, hipMalloc(&tmp, (size_t)h * w * 3 * 4));
         HIPCK(c, hipMemcpyAsync(tmp, image_chw, (size_t)h * w * 3 * 4, hipMemcpyHostToDevice, c->stream)); src = (const float *)tmp;
     }
+    c->stem_u8 = nullptr;
     hipError_t e = launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "letterbox: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
