@@ -111,7 +111,8 @@ def v3_416(hiplib):
 
 def test_full_size_boxes_vs_oracle_one_image(hiplib, v3_416):
     """YOLOv3-416 (BASELINE config), one image: device boxes vs the fp32 oracle in TF semantics.
-    Stated tolerance: fp32 path IoU >= 0.999 and |dscore| <= 1e-3; bf16 path IoU >= 0.95 and |dscore| <= 3e-2 for
+    Stated tolerance: fp32 path IoU >= 0.999 and |dscore| <= 1e-3; bf16 path IoU >= 0.99 and |dscore| <= 1e-2 (the bounds of
+    tests/test_gpu_tuned.py, which covers all 32 images), fp16 storage IoU >= 0.998 and |dscore| <= 1e-3, for
     every oracle box whose score clears the threshold by more than that margin (threshold-flip band reported apart)."""
     eng, txt, flat, img = v3_416
     osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
@@ -120,9 +121,9 @@ def test_full_size_boxes_vs_oracle_one_image(hiplib, v3_416):
     ref = R.yolo_v3_detections(heads, 416, ratio=True)[0]
     rb, rs, rc, ridx = R.select_threshold(ref, 0.5)
     assert len(rs) > 5
-    for dtype, iou_min, ds in ((hiplib.FP32, 0.999, 1e-3), (hiplib.BF16, 0.95, 3e-2)):
-        e = eng if dtype == hiplib.BF16 else hiplib.Engine(txt, max_batch=1, dtype=hiplib.FP32)
-        if dtype == hiplib.FP32:
+    for dtype, iou_min, ds in ((hiplib.FP32, 0.999, 1e-3), (hiplib.BF16, 0.99, 1e-2), (hiplib.FP16, 0.998, 1e-3)):
+        e = eng if dtype == hiplib.BF16 else hiplib.Engine(txt, max_batch=1, dtype=dtype)
+        if dtype != hiplib.BF16:
             e.set_weights(flat)
         det = e.forward(img[:1])[0]
         gb, gs, gc, gidx = R.select_threshold(det, 0.5)
@@ -136,7 +137,7 @@ def test_full_size_boxes_vs_oracle_one_image(hiplib, v3_416):
             assert _iou(rb[k], gb[j]) >= iou_min and abs(rs[k] - gs[j]) <= ds
             checked += 1
         assert checked > 3
-        if dtype == hiplib.FP32:
+        if dtype != hiplib.BF16:
             e.close()
 
 

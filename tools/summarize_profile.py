@@ -58,9 +58,11 @@ def is_conv(k):
 
 
 def last_forward(rows):
-    """the dispatches of the LAST forward: everything from the last k_preprocess dispatch on (tools/prof_forward.py runs
-    one default-plan forward and then ITERS tuned ones; each forward starts with exactly one k_preprocess launch)"""
+    """the dispatches of the LAST forward: everything from the last k_preprocess (or, without one, fused-stem) dispatch on
+    (tools/prof_forward.py runs one default-plan forward and then ITERS tuned ones; each forward starts with exactly one such launch)"""
     starts = [i for i, r in enumerate(rows) if "k_preprocess" in r[1]]
+    if not starts:          # round 3: the fused stem reads the uint8 image itself -- a forward starts with the stem launch
+        starts = [i for i, r in enumerate(rows) if "conv_stem_c32_c64" in r[1]]
     return rows[starts[-1]:] if starts else rows
 
 
@@ -80,7 +82,7 @@ if fetch and write:
     f_tot = sum(v["sum"] for v in f_det.values()); w_tot = sum(v["sum"] for v in w_det.values())
     json.dump({
         "workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
-        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; forwards segmented at the k_preprocess dispatch; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md",
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; forwards segmented at their first dispatch (k_preprocess / the fused stem); KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md",
         "source_hash": build_hash(),
         "conv_launches": sum(v["launches"] for v in f_det.values()),
         "conv_fetch_size_kib_raw": f_tot, "conv_write_size_kib": w_tot,
@@ -105,7 +107,7 @@ if mf:
         e["eff_clock_ghz"] = (gui / 8.0) / ns if gui and ns else None
     tb = sum(r.get("SQ_VALU_MFMA_BUSY_CYCLES") or 0 for r in rows.values()); tg = sum(r.get("GRBM_GUI_ACTIVE") or 0 for r in rows.values())
     json.dump({"workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
-               "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; forwards segmented at the k_preprocess dispatch; util = busy/(256 CUs*4 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs)",
+               "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; forwards segmented at their first dispatch (k_preprocess / the fused stem); util = busy/(256 CUs*4 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs)",
                "source_hash": build_hash(),
                "conv_launches": sum(r["launches"] for r in rows.values()),
                "all_conv_mfma_util": (tb / 1024.0) / (tg / 8.0) if tg else None,
