@@ -6,19 +6,19 @@
 // where layer 1 pads), then contracts them with the layer-1 filters held in registers.  HBM sees the 8-channel image
 // once and the layer-1 output once.
 //
-//   input    the 19 x 35 input pixels (16 B each) a tile needs are gathered into LDS by LDS-DMA one tile AHEAD (double
+//   input    the 19 x 35 input pixels (16 B each) a tile needs are gathered into LDS by LDS-DMA two tiles AHEAD (double
 //            buffered), so no wave ever waits on global-memory latency inside a tile; image borders are zero-filled
 //            by the buffer range check.
-//   phase A  one 16-pixel group per step and wave: a lane's B fragment for K-group (kk, lq) is the 16-byte channel
+//   phase A  (producer waves) one 16-pixel group per step and wave: a lane's B fragment for K-group (kk, lq) is the 16-byte channel
 //            vector of ONE input pixel (tap kk*4+lq), one ds_read_b128; 6 MFMAs; the 4 channels a lane ends up with go
 //            to LDS as one ds_write_b64.  LDS pixel pitch is 80 B: with layer 1's stride-2 access
 //            the 16 lanes of every ds_read_b128 lane group then fall on 16 distinct 16-B bank slots.
-//   phase B  wave w (of 8) owns output row w of the tile (16 pixels) x 64 channels: per tap one ds_read_b128
+//   phase B  (consumer waves) wave w (of 4) owns output rows 2w, 2w+1 of the tile (16 pixels each) x 64 channels: per tap and row one ds_read_b128
 //            (K-step = the tap's 32 channels) feeding 4 MFMAs against register-resident filters.
 //   epilogue through LDS so that the global stores are 16 B per lane, whole 128-B pixel rows.
 // Optional tail: the 1x1 conv 64 -> 32 that follows (darknet-53 layer 2) runs on the staged layer-1 tile before it
 // leaves LDS, so that layer never re-reads its 177 MB input.
-// Workgroups are persistent (one 8-wave workgroup per CU) so the 168 VGPRs of filter fragments are loaded once per wave.
+// Workgroups are persistent (one 8-wave workgroup per CU) so the filter fragments (144 VGPRs of layer 1 in a consumer wave) are loaded once per wave.
 #include "kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -83,9 +83,18 @@ constexpr int ST_B1_BYTES = 64 * 4;                          // layer-1 bias: re
 constexpr int ST_B2_BYTES = 32 * 4;                          // tail bias, in LDS too: a global load inside the tile loop
                                                              // would make hipcc wait vmcnt(0) and drain the input prefetch
 
-// U8: the image is read as the caller's uint8 [N, H, W, 3] itself: the raw rows of a tile are gathered by 4-byte LDS-DMA one tile ahead and
-// converted to the 16-byte pixel records (x * scale [* mul + add], rounded to the storage type: exactly k_preprocess's arithmetic) at the
-// start of their tile -- the separate conversion launch and its [N, H, W, 8] tensor (88 MB written, 88 MB read at 416 x 416 x 32) disappear.
+// U8: the image is read as the caller's uint8 [N, H, W, 3] itself: the raw rows of a tile are gathered by 4-byte LDS-DMA and converted to
+// the 16-byte pixel records (x * scale [* mul + add], rounded to the storage type: exactly k_preprocess's arithmetic) one tile ahead of
+// phase A -- the separate conversion launch and its [N, H, W, 8] tensor (88 MB written, 88 MB read at 416 x 416 x 32) disappear.
+//
+// Wave roles.  Phase A is VALU-bound (bias / leaky / rounding of 32 channels per layer-0 pixel behind three short MFMAs), phase B is
+// MFMA-bound; run one after the other by all eight waves, each left the other pipe idle (ablation, 416 x 416 x 32: A 76, B 41, tail 25,
+// stores 17, conversion 10 of 187 us).  So the workgroup is split: waves 0-3 PRODUCE (phase A of tile i+1 into one half of a
+// double-buffered layer-0 tile), waves 4-7 CONSUME (phase B, epilogue, stores and 1x1 tail of tile i -- two tile rows per wave, staged
+// through wave-private LDS rows, no workgroup barrier -- and the uint8 conversion of tile i+2).  Every SIMD holds one wave of each kind,
+// so its matrix pipe and its VALU are fed from different instruction streams, and ONE barrier per tile moves the pipeline on:
+//   raw rows (LDS-DMA, producers)  tile i+3  ->  records (consumers)  tile i+2  ->  layer-0 tile (producers)  tile i+1  ->  output (consumers)  tile i
+// Only producers issue LDS-DMA (their vmcnt(0) before the barrier is exact); consumers never wait for their global stores.
 template <bool H16, bool U8 = false>
 __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a)
 {
@@ -93,136 +102,105 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-
-    // ---- filters and biases, once per wave ----
-    bf16x8 fw0[2][3], fw1[4][9];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-            fw0[i][kk] = *(const bf16x8 *)((const bf16_t *)a.w0 + (size_t)(i * 16 + l15) * a.Kpad0 + (kk * 4 + lq) * 8);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-            fw1[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w1 + (size_t)(ct * 16 + l15) * a.Kpad1 + t * 32 + lq * 8);
-    f32x4 b0v[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) b0v[i] = *(const f32x4 *)(a.b0 + i * 16 + lq * 4);
+    const int sub = wave & 3;                                    // index among the four waves of this wave's role
     const float slope0 = a.act0 == ACT_LEAKY ? 0.1f : 1.f, slope1 = a.act1 == ACT_LEAKY ? 0.1f : 1.f, slope2 = a.act2 == ACT_LEAKY ? 0.1f : 1.f;
-    // phase A: byte offsets of this lane's taps lq and 4 + lq relative to its pixel in the input tile, packed into one register (the
-    // filter fragments leave none to spare); tap 8 + lq exists for lq == 0 only (the others are K padding: they read the zero slot)
-    const int tap0 = lq, tap1 = 4 + lq;
-    const int tapoff01 = (((tap0 * 11) >> 5) * ST_IW + tap0 - 3 * ((tap0 * 11) >> 5)) * 16 | ((((tap1 * 11) >> 5) * ST_IW + tap1 - 3 * ((tap1 * 11) >> 5)) * 16) << 16;
 
     const int tiles_x = (a.Wo + ST_TW - 1) / ST_TW, tiles_y = (a.Ho + ST_TH - 1) / ST_TH;
     const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
-    // the image is read through a buffer descriptor: an out-of-range offset makes the LDS-DMA write zeros (the padding)
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, 0x80000000u, 0x00020000);
-
-    // gather the 19 x 35 input pixels (16 B each) of `tile` into `dst`: lane-linear 64-pixel pieces, piece c by wave c % 8
-    auto fetch = [&](int tile, char *dst) {
-        const int n = tile / per_img, tr = tile - n * per_img;
-        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int iy0 = 2 * ty * ST_TH - 2, ix0 = 2 * tx * ST_TW - 2;
-#pragma unroll
-        for (int k = 0; k < (ST_INCHUNKS + ST_NW - 1) / ST_NW; ++k) {
-            const int c = wave + ST_NW * k;
-            if (c < ST_INCHUNKS) {
-                const int q = c * 64 + lane;
-                const int ry = (q * 1873) >> 16;                 // q / 35 for q < 704
-                const int rxx = q - ry * ST_IW;
-                const int iy = iy0 + ry, ix = ix0 + rxx;
-                const bool ok = q < ST_INPIX && tile < ntiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.in_stride) * 2u : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (st_lds_void *)(dst + c * 1024), 16, off, 0, 0, 0);
-            }
-        }
-    };
-
-    // (U8: the descriptor ends with the image tensor -- the 4-byte loads of a row's slack must not touch what lies behind it)
-    __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)(U8 ? (const void *)a.in_u8 : a.in), 0, U8 ? (unsigned)(((size_t)a.N * a.H * a.W * 3) & ~(size_t)3) : 0x80000000u, 0x00020000);
-    // U8: byte offset of input pixel (iy0, ix0) of `tile` (may be negative at the left / top border: those bytes are masked at conversion)
+    const int nt = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup: blockIdx.x + j * gridDim.x
+    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    // input pixel (iy0, ix0) = record (0, 0) of `tile` (may be negative at the left / top border)
     auto tile_origin = [&](int tile, int &n, int &iy0, int &ix0) {
         n = tile / per_img; const int tr = tile - n * per_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         iy0 = 2 * ty * ST_TH - 2; ix0 = 2 * tx * ST_TW - 2;
     };
-    auto fetch_raw = [&](int tile, char *dst) {
-        int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
-#pragma unroll
-        for (int k = 0; k < (ST_RAW_PIECES + ST_NW - 1) / ST_NW; ++k) {
-            const int c = wave + ST_NW * k;
-            if (c < ST_RAW_PIECES) {
-                const int g = c * 64 + lane;                         // dword of the tile's raw image: row g / 28, dword g % 28
-                const int r = (g * 2341) >> 16;                      // g / 28 for g < 1170
-                const int d = g - r * (ST_RAW_ROW / 4);
-                const int iy = iy0 + r;
-                const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;    // first byte the row needs
-                const bool ok = g < ST_RAW_DW && tile < ntiles && (unsigned)iy < (unsigned)a.H;
-                const unsigned off = ok ? (unsigned)((s_r & ~3) + 4 * d) : 0x80000000u;      // (a negative offset is out of range too: zeros)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (st_lds_void *)(dst + c * 256), 4, off, 0, 0, 0);
-            }
-        }
-    };
-    // raw rows of `tile` (in `raw`) -> 16-byte pixel records (3 converted channels + 5 zeros) in `pix`; pixels outside the image are zeros
-    auto convert_raw = [&](int tile, const char *__restrict__ raw, char *__restrict__ pix) {
-        int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
-#pragma unroll
-        for (int j = 0; j < (ST_INPIX + 64 * ST_NW - 1) / (64 * ST_NW); ++j) {
-            const int p = tid + j * 64 * ST_NW;
-            if (p < ST_INPIX) {
-                const int ry = (p * 1873) >> 16, rxx = p - ry * ST_IW;       // p / 35
-                const int iy = iy0 + ry, ix = ix0 + rxx;
-                const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;
-                const int b = (s_r & 3) + 3 * rxx;                           // byte of the pixel in its row's LDS slot
-                const unsigned *q = (const unsigned *)(raw + ry * ST_RAW_ROW + (b & ~3));
-                const unsigned x = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(b & 3));
-                float v0 = __fmul_rn((float)(x & 0xffu), a.in_scale), v1 = __fmul_rn((float)((x >> 8) & 0xffu), a.in_scale), v2 = __fmul_rn((float)((x >> 16) & 0xffu), a.in_scale);
-                if (a.in_mul != 1.0f || a.in_add != 0.0f) { v0 = __fadd_rn(__fmul_rn(v0, a.in_mul), a.in_add); v1 = __fadd_rn(__fmul_rn(v1, a.in_mul), a.in_add); v2 = __fadd_rn(__fmul_rn(v2, a.in_mul), a.in_add); }
-                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                *(uint4 *)(pix + p * 16) = ok ? uint4{stem_pk<H16>(v0, v1), stem_pk<H16>(v2, 0.f), 0u, 0u} : uint4{0u, 0u, 0u, 0u};
-            }
-        }
-    };
 
-    // One tile.  Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling
-    // `in_next` cannot alias the reads below, instead of waiting vmcnt(0) before the first ds_read after it.
-    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur_,
-                       char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2, char *__restrict__ pix) {
-        const char *__restrict__ in_cur = in_cur_;
-        if constexpr (U8) {
-            fetch_raw(next_tile, in_next);                       // lands during this tile
-            convert_raw(tile, in_cur_, pix);                     // (its raw rows landed during the previous tile)
-            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this thread's records are written
-            __builtin_amdgcn_s_barrier();
-            in_cur = pix;
-        } else
-            fetch(next_tile, in_next);                           // lands during this tile's two phases
-        const int n = tile / per_img, tr = tile - n * per_img;
-        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
-        const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;          // layer-0 coordinates of LDS pixel (0, 0)
+    // LDS: [raw rows x 2 (U8) | pixel records x 2 | layer-0 tile x 2 | staged layer-1 tile | staged tail tile | tail filters, biases]
+    constexpr int RAWB = U8 ? ST_RAW_BYTES : 0;
+    char *const raw0 = smem, *const raw1 = smem + RAWB;
+    char *const pix0 = smem + 2 * RAWB, *const pix1 = pix0 + ST_IN_BYTES;
+    char *const l00 = pix1 + ST_IN_BYTES, *const l01 = l00 + ST_L0_BYTES;
+    char *const lo = l01 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
+    if (a.w2)                                                    // tail filters -> LDS, 16 B per thread (256 pieces)
+        if (tid < 32 * 8) {
+            const int row = tid >> 3, piece = tid & 7;
+            *(uint4 *)(lw2 + row * ST_W2PITCH + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
+            if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
+        }
+    if (tid < 64) *(float *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + tid * 4) = a.b1[tid];
+    if (tid < 4) { ((uint32_t *)(pix0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(pix1 + ST_INCHUNKS * 1024))[tid] = 0; }   // the zero slot of the K padding
 
-        // ---- phase A: layer-0 pixels of this tile -> LDS; a lane's B fragment (kk, lq) = input pixel of tap kk*4+lq ----
-        constexpr int ROUNDS = (ST_GROUPS + ST_NW - 1) / ST_NW;
-        // The loop stays rolled: unrolled, the per-round offsets are hoisted out of the tile loop and spill (168 VGPRs hold
-        // filters).  (Reading round j+1's fragments during round j was tried: +10 % time, the register copies cost more
-        // than the exposed LDS latency with two waves per SIMD.)
-#pragma unroll 1
-        for (int j = 0; j < ROUNDS; ++j) {
-            const int g = wave + ST_NW * j;
-            if (g < ST_GROUPS) {
-                const int idx = g * 16 + l15;
+    if (wave < 4) {
+        // =========================================== producers ===========================================
+        bf16x8 fw0[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk)
+                fw0[i][kk] = *(const bf16x8 *)((const bf16_t *)a.w0 + (size_t)(i * 16 + l15) * a.Kpad0 + (kk * 4 + lq) * 8);
+        f32x4 b0v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b0v[i] = *(const f32x4 *)(a.b0 + i * 16 + lq * 4);
+        // byte offsets of this lane's taps lq and 4 + lq relative to its pixel in the record tile; tap 8 + lq exists for lq == 0 only
+        // (the others are K padding: they read the zero slot)
+        const int tap0 = lq, tap1 = 4 + lq;
+        const int tapoff0 = (((tap0 * 11) >> 5) * ST_IW + tap0 - 3 * ((tap0 * 11) >> 5)) * 16, tapoff1 = (((tap1 * 11) >> 5) * ST_IW + tap1 - 3 * ((tap1 * 11) >> 5)) * 16;
+        // the image is read through a buffer descriptor: an out-of-range offset makes the LDS-DMA write zeros (the padding); U8: the
+        // descriptor ends with the image tensor -- the 4-byte loads of a row's slack must not touch what lies behind it
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(U8 ? (const void *)a.in_u8 : a.in), 0, U8 ? (unsigned)(((size_t)a.N * a.H * a.W * 3) & ~(size_t)3) : 0x80000000u, 0x00020000);
+
+        // gather the 19 x 35 input pixels of `tile` into `dst`: pieces of 64 lanes, piece c by producer wave c % 4
+        auto fetch = [&](int tile, char *dst) {
+            int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
+            if constexpr (U8) {
+#pragma unroll
+                for (int k = 0; k < (ST_RAW_PIECES + 3) / 4; ++k) {
+                    const int c = sub + 4 * k;
+                    if (c < ST_RAW_PIECES) {
+                        const int g = c * 64 + lane;                         // dword of the tile's raw image: row g / 28, dword g % 28
+                        const int r = (g * 2341) >> 16;                      // g / 28 for g < 1170
+                        const int d = g - r * (ST_RAW_ROW / 4);
+                        const int iy = iy0 + r;
+                        const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;    // first byte the row needs
+                        const bool ok = g < ST_RAW_DW && (unsigned)iy < (unsigned)a.H;
+                        const unsigned off = ok ? (unsigned)((s_r & ~3) + 4 * d) : 0x80000000u;      // (a negative offset is out of range too: zeros)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (st_lds_void *)(dst + c * 256), 4, off, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (ST_INCHUNKS + 3) / 4; ++k) {
+                    const int c = sub + 4 * k;
+                    if (c < ST_INCHUNKS) {
+                        const int q = c * 64 + lane;
+                        const int ry = (q * 1873) >> 16;                 // q / 35 for q < 704
+                        const int rxx = q - ry * ST_IW;
+                        const int iy = iy0 + ry, ix = ix0 + rxx;
+                        const bool ok = q < ST_INPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        const unsigned off = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.in_stride) * 2u : 0x80000000u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (st_lds_void *)(dst + c * 1024), 16, off, 0, 0, 0);
+                    }
+                }
+            }
+        };
+        // phase A: the 17 x 33 layer-0 pixels of `tile` (its records in `in_cur`) -> `l0`; one 16-pixel group per step, a lane's B
+        // fragment (kk, lq) = the record of tap kk*4+lq.  36 groups = 9 per producer wave.
+        auto phase_a = [&](int tile, const char *__restrict__ in_cur, char *__restrict__ l0) {
+            int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
+            const int gy0 = iy0 + 1, gx0 = ix0 + 1;              // layer-0 coordinates of LDS pixel (0, 0)
+#pragma unroll 3
+            for (int j = 0; j < ST_GROUPS / 4; ++j) {
+                const int idx = (sub + 4 * j) * 16 + l15;
                 const int ly = (idx * 1986) >> 16;               // idx / 33 for idx < 576
                 const int lx = idx - ly * ST_LW;
                 const bool inside = idx < ST_NPIX && (unsigned)(gy0 + ly) < (unsigned)a.H && (unsigned)(gx0 + lx) < (unsigned)a.W;
-                // layer-0 pixel (ly, lx) sits at input-region pixel (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw).  (The
-                // rows past the tile, idx >= ST_NPIX, read defined bytes of the fetched pieces and are zeroed below.)
+                // layer-0 pixel (ly, lx) sits at record (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw).  (The rows past
+                // the tile, idx >= ST_NPIX, read defined bytes of the fetched pieces and are zeroed below.)
                 const int pbase = (ly * ST_IW + lx) * 16;
                 bf16x8 fx[3];
-                fx[0] = *(const bf16x8 *)(in_cur + pbase + (tapoff01 & 0xffff));
-                fx[1] = *(const bf16x8 *)(in_cur + pbase + (tapoff01 >> 16));
+                fx[0] = *(const bf16x8 *)(in_cur + pbase + tapoff0);
+                fx[1] = *(const bf16x8 *)(in_cur + pbase + tapoff1);
                 fx[2] = *(const bf16x8 *)(in_cur + (lq == 0 ? pbase + (2 * ST_IW + 2) * 16 : ST_INCHUNKS * 1024));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -234,91 +212,133 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                     *(uint2 *)(l0 + idx * ST_PITCH + (i * 16 + lq * 4) * 2) = pk;
                 }
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes are done
+        };
+        // Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling `dma_dst`
+        // cannot alias phase A's reads, instead of waiting vmcnt(0) before the first ds_read after it.
+        auto produce = [&](int i, char *__restrict__ dma_dst, const char *__restrict__ in_cur, char *__restrict__ l0) {
+            const int jf = i + (U8 ? 3 : 2);                     // tile whose input is fetched during this step
+            if (jf < nt) fetch(tile_of(jf), dma_dst);
+            if (i + 1 >= 0 && i + 1 < nt) phase_a(tile_of(i + 1), in_cur, l0);
+        };
+        static_assert(ST_GROUPS % 4 == 0, "phase A: whole groups per producer wave");
+        if constexpr (U8) fetch(tile_of(0), raw0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-
-        // ---- phase B: 16 layer-1 pixels (tile row `wave`) x 64 channels per wave ----
-        f32x4 acc1[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char *xb = l0 + ((2 * wave) * ST_LW + 2 * l15) * ST_PITCH + lq * 16;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int kh = t / 3, kw = t - kh * 3;
-            const bf16x8 x = *(const bf16x8 *)(xb + (kh * ST_LW + kw) * ST_PITCH);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc1[ct] = stem_mma<H16>(fw1[ct][t], x, acc1[ct]);
+        for (int i = -2; i < nt; ++i) {
+            if (i & 1) produce(i, U8 ? raw0 : pix1, pix0, l00);
+            else produce(i, U8 ? raw1 : pix0, pix1, l01);
+            __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the fetched input has landed, the layer-0 tile is written
+            __builtin_amdgcn_s_barrier();
         }
-        // ---- epilogue: bias + activation -> bf16 -> LDS -> 16-B stores ----
+    } else {
+        // =========================================== consumers ===========================================
+        bf16x8 fw1[4][9];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc1[ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
-        }
-        // staged tile complete, every wave done with the layer-0 tile, and the next tile's input has landed
-        __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int it = 0; it < ST_TH * ST_TW * 8 / (64 * ST_NW); ++it) {
-            const int c = tid + it * 64 * ST_NW;
-            const int px = c >> 3, chunk = c & 7;
-            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
-            if (oy < a.Ho && ox < a.Wo)
-                *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) = *(const uint4 *)(lo + px * ST_OPITCH + chunk * 16);
-        }
-        if (a.w2) {
-            // ---- tail: 1x1 conv 64 -> 32 on the staged layer-1 tile (its bf16 values, exactly what a separate launch
-            //      would have re-read from HBM): wave w = tile row w, 2 channel tiles x 2 K-steps ----
-            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int t = 0; t < 9; ++t)
+                fw1[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w1 + (size_t)(ct * 16 + l15) * a.Kpad1 + t * 32 + lq * 8);
+        const int ctid = tid - 256;
+        // raw rows of `tile` (in `raw`) -> 16-byte pixel records (3 converted channels + 5 zeros) in `pix`; pixels outside the image are zeros
+        auto convert_raw = [&](int tile, const char *__restrict__ raw, char *__restrict__ pix) {
+            int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 x = *(const bf16x8 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bf16x8 w = *(const bf16x8 *)(lw2 + (i * 16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
-                    acc2[i] = stem_mma<H16>(w, x, acc2[i]);
+            for (int j = 0; j < (ST_INPIX + 255) / 256; ++j) {
+                const int p = ctid + j * 256;
+                if (p < ST_INPIX) {
+                    const int ry = (p * 1873) >> 16, rxx = p - ry * ST_IW;       // p / 35
+                    const int iy = iy0 + ry, ix = ix0 + rxx;
+                    const int s_r = ((n * a.H + iy) * a.W + ix0) * 3;
+                    const int b = (s_r & 3) + 3 * rxx;                           // byte of the pixel in its row's LDS slot
+                    const unsigned *q = (const unsigned *)(raw + ry * ST_RAW_ROW + (b & ~3));
+                    const unsigned x = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(b & 3));
+                    float v0 = __fmul_rn((float)(x & 0xffu), a.in_scale), v1 = __fmul_rn((float)((x >> 8) & 0xffu), a.in_scale), v2 = __fmul_rn((float)((x >> 16) & 0xffu), a.in_scale);
+                    if (a.in_mul != 1.0f || a.in_add != 0.0f) { v0 = __fadd_rn(__fmul_rn(v0, a.in_mul), a.in_add); v1 = __fadd_rn(__fmul_rn(v1, a.in_mul), a.in_add); v2 = __fadd_rn(__fmul_rn(v2, a.in_mul), a.in_add); }
+                    const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    *(uint4 *)(pix + p * 16) = ok ? uint4{stem_pk<H16>(v0, v1), stem_pk<H16>(v2, 0.f), 0u, 0u} : uint4{0u, 0u, 0u, 0u};
                 }
             }
+        };
+        // phase B of `tile`: this wave owns tile rows 2*sub and 2*sub+1 (16 pixels each) x 64 channels; per tap two ds_read_b128 (K-step =
+        // the tap's 32 channels) feed 8 MFMAs against register-resident filters.  Epilogue, stores and the 1x1 tail go through this wave's
+        // own rows of the staged tiles: LDS is in order within a wave, so no workgroup barrier separates them.
+        auto phase_b = [&](int tile, const char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2) {
+            const int n = tile / per_img, tr = tile - n * per_img;
+            const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+            const int oy0 = ty * ST_TH + 2 * sub, ox0 = tx * ST_TW;
+            f32x4 acc1[2][4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 bv = *(const f32x4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4);
-                *(uint2 *)(lo2 + (wave * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[i], bv, slope2);
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc1[r][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char *xb = l0 + ((4 * sub) * ST_LW + 2 * l15) * ST_PITCH + lq * 16;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - kh * 3;
+                const bf16x8 x0 = *(const bf16x8 *)(xb + (kh * ST_LW + kw) * ST_PITCH);
+                const bf16x8 x1 = *(const bf16x8 *)(xb + ((kh + 2) * ST_LW + kw) * ST_PITCH);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) { acc1[0][ct] = stem_mma<H16>(fw1[ct][t], x0, acc1[0][ct]); acc1[1][ct] = stem_mma<H16>(fw1[ct][t], x1, acc1[1][ct]); }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_s_barrier();
-            {
-                const int px = tid >> 2, chunk = tid & 3;        // 128 pixels x 4 pieces of 16 B
+            char *const lrow = lo + (2 * sub) * ST_TW * ST_OPITCH;           // this wave's 32 staged pixels
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    *(uint2 *)(lrow + (r * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc1[r][ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {                                 // 32 pixels x 8 pieces of 16 B: whole 128-B pixel rows
+                const int c = lane + it * 64;
+                const int px = c >> 3, chunk = c & 7;
                 const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
                 if (oy < a.Ho && ox < a.Wo)
-                    *(uint4 *)((bf16_t *)a.out2 + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out2_stride + chunk * 8) = *(const uint4 *)(lo2 + px * ST_O2PITCH + chunk * 16);
+                    *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) = *(const uint4 *)(lrow + px * ST_OPITCH + chunk * 16);
             }
+            if (a.w2) {
+                // ---- tail: 1x1 conv 64 -> 32 on the staged layer-1 rows (their stored values, exactly what a separate launch would
+                //      have re-read from HBM): 2 rows x 2 channel tiles x 2 K-steps ----
+                f32x4 acc2[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { acc2[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[r][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 w0 = *(const bf16x8 *)(lw2 + l15 * ST_W2PITCH + (kk * 4 + lq) * 16), w1 = *(const bf16x8 *)(lw2 + (16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const bf16x8 x = *(const bf16x8 *)(lrow + (r * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
+                        acc2[r][0] = stem_mma<H16>(w0, x, acc2[r][0]); acc2[r][1] = stem_mma<H16>(w1, x, acc2[r][1]);
+                    }
+                }
+                char *const lrow2 = lo2 + (2 * sub) * ST_TW * ST_O2PITCH;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        *(uint2 *)(lrow2 + (r * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[r][i], *(const f32x4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4), slope2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {                             // 32 pixels x 4 pieces of 16 B
+                    const int c = lane + it * 64;
+                    const int px = c >> 2, chunk = c & 3;
+                    const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+                    if (oy < a.Ho && ox < a.Wo)
+                        *(uint4 *)((bf16_t *)a.out2 + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out2_stride + chunk * 8) = *(const uint4 *)(lrow2 + px * ST_O2PITCH + chunk * 16);
+                }
+            }
+        };
+        auto consume = [&](int i, const char *__restrict__ l0, const char *__restrict__ raw, char *__restrict__ pix) {
+            if (i >= 0) phase_b(tile_of(i), l0, lo, lo2, lw2);
+            if constexpr (U8) { if (i + 2 < nt) convert_raw(tile_of(i + 2), raw, pix); }
+        };
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        for (int i = -2; i < nt; ++i) {
+            if (i & 1) consume(i, l01, raw1, pix1);
+            else consume(i, l00, raw0, pix0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the records are written, the layer-0 tile is read
+            __builtin_amdgcn_s_barrier();
         }
-        // the next tile's phase A writes l0 (free since the first barrier of the epilogue) and its staged-tile writes come
-        // after its own first barrier, by which time every thread has finished the reads of `lo` / `lo2` above
-    };
-
-    // LDS: [input buffer 0 | input buffer 1 | layer-0 tile | staged tiles | tail filters, biases]; U8: the two input buffers hold raw rows
-    // (2304 B each) and the pixel records of the CURRENT tile follow them
-    constexpr int INB = U8 ? ST_RAW_BYTES : ST_IN_BYTES;
-    char *const inb0 = smem, *const inb1 = smem + INB;
-    char *const pixb = smem + 2 * INB;
-    char *const l0 = pixb + (U8 ? ST_IN_BYTES : 0), *const lo = l0 + ST_L0_BYTES, *const lo2 = lo + ST_OUT_BYTES, *const lw2 = lo2 + ST_OUT2_BYTES;
-    if (a.w2)                                                    // tail filters -> LDS, 16 B per thread (256 pieces)
-        if (tid < 32 * 8) {
-            const int row = tid >> 3, piece = tid & 7;
-            *(uint4 *)(lw2 + row * ST_W2PITCH + piece * 16) = *(const uint4 *)((const bf16_t *)a.w2 + (size_t)row * a.Kpad2 + piece * 8);
-            if (tid < 32) *(float *)(lw2 + ST_W2_BYTES + tid * 4) = a.b2[tid];
-        }
-    if (tid < 64) *(float *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + tid * 4) = a.b1[tid];
-    if constexpr (U8) { if (tid < 4) ((uint32_t *)(pixb + ST_INCHUNKS * 1024))[tid] = 0; }           // the zero slot of the K padding
-    else if (tid < 4) { ((uint32_t *)(inb0 + ST_INCHUNKS * 1024))[tid] = 0; ((uint32_t *)(inb1 + ST_INCHUNKS * 1024))[tid] = 0; }
-    int tile = blockIdx.x;
-    if (tile < ntiles) { if constexpr (U8) fetch_raw(tile, inb0); else fetch(tile, inb0); }
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_s_barrier();
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, l0, lo, lo2, lw2, pixb);
-        else do_tile(tile, tile + gridDim.x, inb1, inb0, l0, lo, lo2, lw2, pixb);
     }
 #endif
 }
@@ -491,13 +511,12 @@ bool conv_stem_ok(const StemArgs &a)
 hipError_t launch_conv_stem(const StemArgs &a, hipStream_t s)
 {
     if (!conv_stem_ok(a)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * ST_IN_BYTES + ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES + ST_B1_BYTES;
     const bool h16 = a.dt == DT_F16, u8 = a.in_u8 != nullptr;
     if (u8 && (double)a.N * a.H * a.W * 3 >= 2147483648.0) return hipErrorInvalidValue;
+    const size_t ldsb = (size_t)(u8 ? 2 * ST_RAW_BYTES : 0) + 2 * ST_IN_BYTES + 2 * ST_L0_BYTES + ST_OUT_BYTES + ST_OUT2_BYTES + ST_W2_BYTES + ST_B2_BYTES + ST_B1_BYTES;
     const void *k = h16 ? (u8 ? (const void *)conv_stem_c32_c64<true, true> : (const void *)conv_stem_c32_c64<true, false>)
                         : (u8 ? (const void *)conv_stem_c32_c64<false, true> : (const void *)conv_stem_c32_c64<false, false>);
-    { hipError_t e = conv_opt_in_lds(k, lds + (u8 ? 2 * ST_RAW_BYTES : 0)); if (e != hipSuccess) return e; }
-    const size_t ldsb = u8 ? lds - ST_IN_BYTES + 2 * ST_RAW_BYTES : lds;
+    { hipError_t e = conv_opt_in_lds(k, ldsb); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.Wo + ST_TW - 1) / ST_TW) * ((a.Ho + ST_TH - 1) / ST_TH);
     long blocks = 256; if (blocks > tiles) blocks = tiles;          // persistent: one workgroup per CU
     if (h16 && u8) hipLaunchKernelGGL((conv_stem_c32_c64<true, true>), dim3((unsigned)blocks), dim3(64 * ST_NW), ldsb, s, a);
