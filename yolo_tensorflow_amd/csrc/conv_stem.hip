@@ -20,6 +20,7 @@
 // leaves LDS, so that layer never re-reads its 177 MB input.
 // Workgroups are persistent (one 8-wave workgroup per CU) so the filter fragments (144 VGPRs of layer 1 in a consumer wave) are loaded once per wave.
 #include "kernels.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -66,6 +67,7 @@ constexpr int ST_OUT_BYTES = ST_TH * ST_TW * ST_OPITCH;       // 18432
 
 constexpr int ST_NW = 8;                             // waves per workgroup == ST_TH
 typedef __attribute__((address_space(3))) void st_lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
 constexpr int ST_IH = ST_LH + 2, ST_IW = ST_LW + 2;          // input pixels a tile needs: 19 x 35
 constexpr int ST_INPIX = ST_IH * ST_IW;                      // 665
 constexpr int ST_INCHUNKS = (ST_INPIX + 63) / 64;            // 64-pixel LDS-DMA pieces: 11
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(U8 ? (const void *)a.in_u8 : a.in), 0, U8 ? (unsigned)(((size_t)a.N * a.H * a.W * 3) & ~(size_t)3) : 0x80000000u, 0x00020000);
 
         // gather the 19 x 35 input pixels of `tile` into `dst`: pieces of 64 lanes, piece c by producer wave c % 4
-        auto fetch = [&](int tile, char *dst) {
+        auto fetch = [&](int tile, lds_char *dst) {
             int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
             if constexpr (U8) {
 #pragma unroll
@@ -185,48 +187,87 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             }
         };
         // phase A: the 17 x 33 layer-0 pixels of `tile` (its records in `in_cur`) -> `l0`; one 16-pixel group per step, a lane's B
-        // fragment (kk, lq) = the record of tap kk*4+lq.  36 groups = 9 per producer wave.
-        auto phase_a = [&](int tile, const char *__restrict__ in_cur, char *__restrict__ l0) {
+        // fragment (kk, lq) = the record of tap kk*4+lq.  36 groups = 9 per producer wave, and everything about a group except the
+        // image border is the same in every tile: the three record offsets of each group live in registers (a producer wave has them
+        // to spare), the layer-0 address is linear in the group.  Three groups are in flight at a time (reads, 18 MFMAs, epilogues).
+        constexpr int NG = ST_GROUPS / 4;
+        typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_p;
+        typedef __attribute__((address_space(3))) uint2 *lds_u2_p;
+        // (the addresses below carry the LDS address of buffer 0; phase A's `in_cur` / `l0` parameters are then the byte distance of the
+        // buffer in use from buffer 0 -- a constant that folds into the instruction's offset field, no per-read address add)
+        const uint32_t pixa = (uint32_t)(uintptr_t)(lds_char *)pix0, l0a = (uint32_t)(uintptr_t)(lds_char *)l00;
+        uint32_t rd0[NG], rd1[NG], rd2[NG]; int lyx[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = (sub + 4 * j) * 16 + l15;
+            const int ly = (idx * 1986) >> 16;                   // idx / 33 for idx < 576
+            const int lx = idx - ly * ST_LW;
+            // layer-0 pixel (ly, lx) sits at record (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw).  (The rows past the
+            // tile, idx >= ST_NPIX, read defined bytes of the fetched pieces and are zeroed below.)
+            const int pbase = (ly * ST_IW + lx) * 16;
+            rd0[j] = pixa + pbase + tapoff0; rd1[j] = pixa + pbase + tapoff1; rd2[j] = pixa + (lq == 0 ? pbase + (2 * ST_IW + 2) * 16 : ST_INCHUNKS * 1024);
+            lyx[j] = idx < ST_NPIX ? (ly | lx << 8) : 0x7f7f;    // (past the tile: never inside)
+            asm volatile("" : "+v"(rd0[j]), "+v"(rd1[j]), "+v"(rd2[j]));     // (held, not recomputed from their parts at every use)
+        }
+        const uint32_t wr = l0a + (sub * 16 + l15) * ST_PITCH + lq * 8;      // + j * 64 * ST_PITCH + i * 32
+        const bool past = sub == 3 && l15 >= 1;                  // the last group holds ONE pixel of the tile (561 = 35 * 16 + 1)
+        auto phase_a = [&](int tile, const lds_char *__restrict__ in_cur, lds_char *__restrict__ l0) {
             int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
             const int gy0 = iy0 + 1, gx0 = ix0 + 1;              // layer-0 coordinates of LDS pixel (0, 0)
-#pragma unroll 3
-            for (int j = 0; j < ST_GROUPS / 4; ++j) {
-                const int idx = (sub + 4 * j) * 16 + l15;
-                const int ly = (idx * 1986) >> 16;               // idx / 33 for idx < 576
-                const int lx = idx - ly * ST_LW;
-                const bool inside = idx < ST_NPIX && (unsigned)(gy0 + ly) < (unsigned)a.H && (unsigned)(gx0 + lx) < (unsigned)a.W;
-                // layer-0 pixel (ly, lx) sits at record (ly + 1, lx + 1); tap (kh, kw) reads (ly + kh, lx + kw).  (The rows past
-                // the tile, idx >= ST_NPIX, read defined bytes of the fetched pieces and are zeroed below.)
-                const int pbase = (ly * ST_IW + lx) * 16;
-                bf16x8 fx[3];
-                fx[0] = *(const bf16x8 *)(in_cur + pbase + tapoff0);
-                fx[1] = *(const bf16x8 *)(in_cur + pbase + tapoff1);
-                fx[2] = *(const bf16x8 *)(in_cur + (lq == 0 ? pbase + (2 * ST_IW + 2) * 16 : ST_INCHUNKS * 1024));
+            // a tile whose 17 x 33 layer-0 pixels all lie inside the image (every tile but the top row and the left column) needs no
+            // per-pixel test
+            const bool interior = gy0 >= 0 && gx0 >= 0 && gy0 + ST_LH <= a.H && gx0 + ST_LW <= a.W;
+            auto run = [&](auto interior_c) {
+                constexpr bool INT = decltype(interior_c)::value;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int jj = 0; jj < NG; jj += 3) {
+                    bf16x8 fx[3][3];
 #pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) acc = stem_mma<H16>(fw0[i][kk], fx[kk], acc);
-                    uint2 pk = stem_epi<H16>(acc, b0v[i], slope0);
-                    if (!inside) pk = uint2{0, 0};               // layer 1's zero padding, and the unused tail rows
-                    *(uint2 *)(l0 + idx * ST_PITCH + (i * 16 + lq * 4) * 2) = pk;
+                    for (int u = 0; u < 3; ++u) {
+                        fx[u][0] = *(lds_frag_p)(in_cur + rd0[jj + u]);
+                        fx[u][1] = *(lds_frag_p)(in_cur + rd1[jj + u]);
+                        fx[u][2] = *(lds_frag_p)(in_cur + rd2[jj + u]);
+                    }
+                    f32x4 acc[3][2];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            acc[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kk = 0; kk < 3; ++kk) acc[u][i] = stem_mma<H16>(fw0[i][kk], fx[u][kk], acc[u][i]);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int j = jj + u;
+                        bool zero;                               // layer 1's zero padding, and the unused tail of the last group
+                        if constexpr (INT) zero = j == NG - 1 && past;
+                        else zero = !(((unsigned)(gy0 + (lyx[j] & 0xff)) < (unsigned)a.H) & ((unsigned)(gx0 + (lyx[j] >> 8)) < (unsigned)a.W));
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            uint2 pk = stem_epi<H16>(acc[u][i], b0v[i], slope0);
+                            if (!INT || j == NG - 1) { pk.x = zero ? 0u : pk.x; pk.y = zero ? 0u : pk.y; }
+                            *(lds_u2_p)(l0 + wr + j * 64 * ST_PITCH + i * 32) = pk;
+                        }
+                    }
                 }
-            }
+            };
+            if (interior) run(std::true_type{}); else run(std::false_type{});
         };
         // Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling `dma_dst`
         // cannot alias phase A's reads, instead of waiting vmcnt(0) before the first ds_read after it.
-        auto produce = [&](int i, char *__restrict__ dma_dst, const char *__restrict__ in_cur, char *__restrict__ l0) {
+        auto produce = [&](int i, lds_char *__restrict__ dma_dst, const lds_char *__restrict__ in_cur, lds_char *__restrict__ l0) {
             const int jf = i + (U8 ? 3 : 2);                     // tile whose input is fetched during this step
             if (jf < nt) fetch(tile_of(jf), dma_dst);
             if (i + 1 >= 0 && i + 1 < nt) phase_a(tile_of(i + 1), in_cur, l0);
         };
-        static_assert(ST_GROUPS % 4 == 0, "phase A: whole groups per producer wave");
-        if constexpr (U8) fetch(tile_of(0), raw0);
+        static_assert(ST_GROUPS % 12 == 0, "phase A: whole groups per producer wave, three at a time");
+        if constexpr (U8) fetch(tile_of(0), (lds_char *)raw0);
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
         for (int i = -2; i < nt; ++i) {
-            if (i & 1) produce(i, U8 ? raw0 : pix1, pix0, l00);
-            else produce(i, U8 ? raw1 : pix0, pix1, l01);
+            if (i & 1) produce(i, (lds_char *)(U8 ? raw0 : pix1), (const lds_char *)(uintptr_t)0, (lds_char *)(uintptr_t)0);
+            else produce(i, (lds_char *)(U8 ? raw1 : pix0), (const lds_char *)(uintptr_t)ST_IN_BYTES, (lds_char *)(uintptr_t)ST_L0_BYTES);
             __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the fetched input has landed, the layer-0 tile is written
             __builtin_amdgcn_s_barrier();
         }
