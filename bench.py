@@ -123,6 +123,7 @@ def main():
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
     # (fp16 runs the bf16 configuration's kernels shape for shape: it shares that plan)
     tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, "bf16" if fp16 else args.dtype))
+    tuned = os.environ.get("BENCH_PLAN") or tuned                  # (probes: another plan file for the same workload)
     loaded = False
     if os.path.exists(tuned) and not args.retune:
         try:
