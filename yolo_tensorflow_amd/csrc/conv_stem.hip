@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         if constexpr (U8) fetch(tile_of(0), (lds_char *)raw0);
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-        for (int i = -2; i < nt; ++i) {
+        for (int i = -2; i <= nt; ++i) {                         // (one step past the last tile: the consumers drain it there)
             if (i & 1) produce(i, (lds_char *)(U8 ? raw0 : pix1), (const lds_char *)(uintptr_t)0, (lds_char *)(uintptr_t)0);
             else produce(i, (lds_char *)(U8 ? raw1 : pix0), (const lds_char *)(uintptr_t)ST_IN_BYTES, (lds_char *)(uintptr_t)ST_L0_BYTES);
             __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the fetched input has landed, the layer-0 tile is written
@@ -304,83 +304,123 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 }
             }
         };
-        // phase B of `tile`: this wave owns tile rows 2*sub and 2*sub+1 (16 pixels each) x 64 channels; per tap two ds_read_b128 (K-step =
-        // the tap's 32 channels) feed 8 MFMAs against register-resident filters.  Epilogue, stores and the 1x1 tail go through this wave's
-        // own rows of the staged tiles: LDS is in order within a wave, so no workgroup barrier separates them.
-        auto phase_b = [&](int tile, const char *__restrict__ l0, char *__restrict__ lo, char *__restrict__ lo2, const char *__restrict__ lw2) {
+        // Phase B of a tile: this wave owns tile rows 2*sub and 2*sub+1 (16 pixels each) x 64 channels; per tap and row one ds_read_b128
+        // (K-step = the tap's 32 channels) feeds 4 MFMAs against register-resident filters.  Epilogue, stores and the 1x1 tail go through
+        // this wave's own rows of the staged tiles: LDS is in order within a wave, so no workgroup barrier separates them.
+        // One consumer step is software-pipelined: the 18 tap steps of tile i carry, in their shadow, what is left of tile i-1 -- the
+        // stores of its staged rows, its 1x1 tail and the tail's stores -- and the uint8 conversion of tile i+2; the epilogue of tile i
+        // then overwrites the staged rows.  One straight-line block: stores that must not happen (no previous tile, pixels past the
+        // image) go to an out-of-range buffer offset instead of around a branch.  (Same box: 131.9 -> 129.2 us against the plain
+        // sequence -- the step is bound by what the two waves of a SIMD can issue and by LDS traffic, ~340 KB per tile, not by stalls.)
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, 0x80000000u, 0x00020000);
+        __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w2 ? a.out2 : a.out), 0, 0x80000000u, 0x00020000);
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        char *const lrow = lo + (2 * sub) * ST_TW * ST_OPITCH;           // this wave's 32 staged pixels
+        char *const lrow2 = lo2 + (2 * sub) * ST_TW * ST_O2PITCH;
+        int pn = 0, poy0 = 0, pox0 = 0;                                  // image and origin (this wave's rows) of the previous tile
+        auto consume_p = [&](int i, const char *__restrict__ l0, const char *__restrict__ raw, char *__restrict__ pix, char *__restrict__ lr, char *__restrict__ lr2,
+                             const char *__restrict__ lw2_) {
+            const bool pv = i >= 1;                                      // there is a previous tile whose rows are staged
+            const int tile = tile_of(i < nt ? i : nt - 1);               // (the step after the last tile only drains: its phase B result is not stored)
             const int n = tile / per_img, tr = tile - n * per_img;
             const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-            const int oy0 = ty * ST_TH + 2 * sub, ox0 = tx * ST_TW;
-            f32x4 acc1[2][4];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc1[r][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // ---- previous tile: buffer offsets of its 4 + 2 store pieces (formed where they are used: six registers less across the taps) ----
+            auto piece_off = [&](int it) {
+                const int c = lane + it * 64, px = c >> 3, chunk = c & 7;
+                const int oy = poy0 + (px >> 4), ox = pox0 + (px & 15);
+                return pv && oy < a.Ho && ox < a.Wo ? (unsigned)((((pn * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) * 2) : 0x80000000u;
+            };
+            auto piece2_off = [&](int it) {
+                const int c = lane + it * 64, px = c >> 2, chunk = c & 3;
+                const int oy = poy0 + (px >> 4), ox = pox0 + (px & 15);
+                return pv && a.w2 && oy < a.Ho && ox < a.Wo ? (unsigned)((((pn * a.Ho + oy) * a.Wo + ox) * a.out2_stride + chunk * 8) * 2) : 0x80000000u;
+            };
+            // uint8 conversion of tile i+2: geometry
+            int cn = 0, ciy0 = 0, cix0 = 0; const bool cv = U8 && i + 2 < nt;
+            if (cv) tile_origin(tile_of(i + 2), cn, ciy0, cix0);
+            auto convert_round = [&](int j) {
+                const int p = ctid + j * 256;
+                const int ry = (p * 1873) >> 16, rxx = p - ry * ST_IW;           // p / 35
+                const int iy = ciy0 + ry, ix = cix0 + rxx;
+                const int s_r = ((cn * a.H + iy) * a.W + cix0) * 3;
+                const int b = (s_r & 3) + 3 * rxx;                               // byte of the pixel in its row's LDS slot
+                const unsigned *q = (const unsigned *)(raw + (p < ST_INPIX ? ry * ST_RAW_ROW + (b & ~3) : 0));
+                const unsigned x = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(b & 3));
+                float v0 = __fmul_rn((float)(x & 0xffu), a.in_scale), v1 = __fmul_rn((float)((x >> 8) & 0xffu), a.in_scale), v2 = __fmul_rn((float)((x >> 16) & 0xffu), a.in_scale);
+                if (a.in_mul != 1.0f || a.in_add != 0.0f) { v0 = __fadd_rn(__fmul_rn(v0, a.in_mul), a.in_add); v1 = __fadd_rn(__fmul_rn(v1, a.in_mul), a.in_add); v2 = __fadd_rn(__fmul_rn(v2, a.in_mul), a.in_add); }
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (cv && p < ST_INPIX) *(uint4 *)(pix + p * 16) = ok ? uint4{stem_pk<H16>(v0, v1), stem_pk<H16>(v2, 0.f), 0u, 0u} : uint4{0u, 0u, 0u, 0u};
+            };
             const char *xb = l0 + ((4 * sub) * ST_LW + 2 * l15) * ST_PITCH + lq * 16;
+            u32x4_t sd[2];
+            f32x4 acc2[2][2];
+            bf16x8 tx_[2], tw_[2];
+            auto tail_frags = [&](int kk) {
+                tw_[0] = *(const bf16x8 *)(lw2_ + l15 * ST_W2PITCH + (kk * 4 + lq) * 16); tw_[1] = *(const bf16x8 *)(lw2_ + (16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int kh = t / 3, kw = t - kh * 3;
-                const bf16x8 x0 = *(const bf16x8 *)(xb + (kh * ST_LW + kw) * ST_PITCH);
-                const bf16x8 x1 = *(const bf16x8 *)(xb + ((kh + 2) * ST_LW + kw) * ST_PITCH);
+                for (int r = 0; r < 2; ++r) tx_[r] = *(const bf16x8 *)(lr + (r * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
+            };
+            auto tail_mma = [&]() {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) { acc1[0][ct] = stem_mma<H16>(fw1[ct][t], x0, acc1[0][ct]); acc1[1][ct] = stem_mma<H16>(fw1[ct][t], x1, acc1[1][ct]); }
-            }
-            char *const lrow = lo + (2 * sub) * ST_TW * ST_OPITCH;           // this wave's 32 staged pixels
+                for (int r = 0; r < 2; ++r) { acc2[r][0] = stem_mma<H16>(tw_[0], tx_[r], acc2[r][0]); acc2[r][1] = stem_mma<H16>(tw_[1], tx_[r], acc2[r][1]); }
+            };
+            // The wave's two tile rows one after the other (16 accumulator registers at a time, not 32): 18 steps of four MFMAs; the first
+            // row's epilogue rides with the second row's taps.
+            f32x4 accr[2][4];
+            auto epilogue = [&](int r, int c0) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int ct = c0; ct < c0 + 2; ++ct)
+                    *(uint2 *)(lr + (r * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(accr[r][ct], *(const f32x4 *)(lw2_ + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
+            };
+            bf16x8 xn = *(const bf16x8 *)xb;                             // fragment of the next step
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    *(uint2 *)(lrow + (r * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc1[r][ct], *(const f32x4 *)(lw2 + ST_W2_BYTES + ST_B2_BYTES + (ct * 16 + lq * 4) * 4), slope1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {                                 // 32 pixels x 8 pieces of 16 B: whole 128-B pixel rows
-                const int c = lane + it * 64;
-                const int px = c >> 3, chunk = c & 7;
-                const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
-                if (oy < a.Ho && ox < a.Wo)
-                    *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out_stride + chunk * 8) = *(const uint4 *)(lrow + px * ST_OPITCH + chunk * 16);
-            }
-            if (a.w2) {
-                // ---- tail: 1x1 conv 64 -> 32 on the staged layer-1 rows (their stored values, exactly what a separate launch would
-                //      have re-read from HBM): 2 rows x 2 channel tiles x 2 K-steps ----
-                f32x4 acc2[2][2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) { acc2[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[r][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 w0 = *(const bf16x8 *)(lw2 + l15 * ST_W2PITCH + (kk * 4 + lq) * 16), w1 = *(const bf16x8 *)(lw2 + (16 + l15) * ST_W2PITCH + (kk * 4 + lq) * 16);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const bf16x8 x = *(const bf16x8 *)(lrow + (r * ST_TW + l15) * ST_OPITCH + (kk * 4 + lq) * 16);
-                        acc2[r][0] = stem_mma<H16>(w0, x, acc2[r][0]); acc2[r][1] = stem_mma<H16>(w1, x, acc2[r][1]);
-                    }
+            for (int h = 0; h < 18; ++h) {
+                const int r = h / 9, t = h - r * 9;
+                // ---- the piece of the older / newer tiles that rides with this step ----
+                if (h == 0) { sd[0] = *(const u32x4_t *)(lr + (lane >> 3) * ST_OPITCH + (lane & 7) * 16); sd[1] = *(const u32x4_t *)(lr + ((lane + 64) >> 3) * ST_OPITCH + (lane & 7) * 16); }
+                if (h == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(0), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(1), 0, 0);
+                    sd[0] = *(const u32x4_t *)(lr + ((lane + 128) >> 3) * ST_OPITCH + (lane & 7) * 16); sd[1] = *(const u32x4_t *)(lr + ((lane + 192) >> 3) * ST_OPITCH + (lane & 7) * 16);
                 }
-                char *const lrow2 = lo2 + (2 * sub) * ST_TW * ST_O2PITCH;
+                if (h == 2) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(2), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(3), 0, 0); }
+                if (h == 3) tail_frags(0);
+                if (h == 4) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        *(uint2 *)(lrow2 + (r * ST_TW + l15) * ST_O2PITCH + (i * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[r][i], *(const f32x4 *)(lw2 + ST_W2_BYTES + (i * 16 + lq * 4) * 4), slope2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {                             // 32 pixels x 4 pieces of 16 B
-                    const int c = lane + it * 64;
-                    const int px = c >> 2, chunk = c & 3;
-                    const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
-                    if (oy < a.Ho && ox < a.Wo)
-                        *(uint4 *)((bf16_t *)a.out2 + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.out2_stride + chunk * 8) = *(const uint4 *)(lrow2 + px * ST_O2PITCH + chunk * 16);
+                    for (int q = 0; q < 2; ++q) { acc2[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    tail_mma();
                 }
+                if (h == 5) tail_frags(1);
+                if (h == 6) tail_mma();
+                if (h == 7) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            *(uint2 *)(lr2 + (q * ST_TW + l15) * ST_O2PITCH + (k * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[q][k], *(const f32x4 *)(lw2_ + ST_W2_BYTES + (k * 16 + lq * 4) * 4), slope2);
+                }
+                if (h == 8) { sd[0] = *(const u32x4_t *)(lr2 + (lane >> 2) * ST_O2PITCH + (lane & 3) * 16); sd[1] = *(const u32x4_t *)(lr2 + ((lane + 64) >> 2) * ST_O2PITCH + (lane & 3) * 16); }
+                if (h == 9) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro2, piece2_off(0), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro2, piece2_off(1), 0, 0); }
+                if (h == 10) epilogue(0, 0);
+                if (h == 11) epilogue(0, 2);
+                if (h == 12) { if constexpr (U8) convert_round(0); }
+                if (h == 14) { if constexpr (U8) convert_round(1); }
+                if (h == 16) { if constexpr (U8) convert_round(2); }
+                // ---- tap t of row r of tile i (its fragment was requested one step earlier: nothing crosses the fence below) ----
+                const bf16x8 x = xn;
+                if (h + 1 < 18) { const int r1 = (h + 1) / 9, t1 = h + 1 - r1 * 9, kh1 = t1 / 3, kw1 = t1 - kh1 * 3; xn = *(const bf16x8 *)(xb + ((kh1 + 2 * r1) * ST_LW + kw1) * ST_PITCH); }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) accr[r][ct] = stem_mma<H16>(fw1[ct][t], x, t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : accr[r][ct]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        auto consume = [&](int i, const char *__restrict__ l0, const char *__restrict__ raw, char *__restrict__ pix) {
-            if (i >= 0) phase_b(tile_of(i), l0, lo, lo2, lw2);
-            if constexpr (U8) { if (i + 2 < nt) convert_raw(tile_of(i + 2), raw, pix); }
+            // ---- epilogue of the second row: with the first row's, it replaces the previous tile's staged rows ----
+            epilogue(1, 0); epilogue(1, 2);
+            pn = n; poy0 = ty * ST_TH + 2 * sub; pox0 = tx * ST_TW;
         };
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-        for (int i = -2; i < nt; ++i) {
-            if (i & 1) consume(i, l01, raw1, pix1);
-            else consume(i, l00, raw0, pix0);
+        for (int i = -2; i <= nt; ++i) {
+            if (i >= 0) { if (i & 1) consume_p(i, l01, raw1, pix1, lrow, lrow2, lw2); else consume_p(i, l00, raw0, pix0, lrow, lrow2, lw2); }
+            else if constexpr (U8) { if (i + 2 < nt) { if (i & 1) convert_raw(tile_of(i + 2), raw1, pix1); else convert_raw(tile_of(i + 2), raw0, pix0); } }
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the records are written, the layer-0 tile is read
             __builtin_amdgcn_s_barrier();
         }
