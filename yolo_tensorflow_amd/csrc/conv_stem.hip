@@ -110,11 +110,19 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
     const int tiles_x = (a.Wo + ST_TW - 1) / ST_TW, tiles_y = (a.Ho + ST_TH - 1) / ST_TH;
     const int per_img = tiles_x * tiles_y, ntiles = a.N * per_img;
     const int nt = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup: blockIdx.x + j * gridDim.x
-    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    // A workgroup walks its tiles in steps of gridDim.x; their (image, tile row, tile column) are carried, not divided out of the tile
+    // index at every use (three integer divisions per decode, ~190 scalar instructions per tile in a wave that is issue-bound).
+    struct TilePos { int n, ty, tx; };
+    auto tile_pos = [&](int tile) { TilePos q; q.n = tile / per_img; const int tr = tile - q.n * per_img; q.ty = tr / tiles_x; q.tx = tr - q.ty * tiles_x; return q; };
+    const TilePos gstep = tile_pos((int)gridDim.x);
+    auto advance = [&](TilePos &q) {
+        q.tx += gstep.tx; q.ty += gstep.ty; q.n += gstep.n;
+        if (q.tx >= tiles_x) { q.tx -= tiles_x; ++q.ty; }
+        if (q.ty >= tiles_y) { q.ty -= tiles_y; ++q.n; }
+    };
     // input pixel (iy0, ix0) = record (0, 0) of `tile` (may be negative at the left / top border)
-    auto tile_origin = [&](int tile, int &n, int &iy0, int &ix0) {
-        n = tile / per_img; const int tr = tile - n * per_img;
-        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    auto tile_origin = [&](const TilePos &q, int &n, int &iy0, int &ix0) {
+        n = q.n; const int ty = q.ty, tx = q.tx;
         iy0 = 2 * ty * ST_TH - 2; ix0 = 2 * tx * ST_TW - 2;
     };
 
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(U8 ? (const void *)a.in_u8 : a.in), 0, U8 ? (unsigned)(((size_t)a.N * a.H * a.W * 3) & ~(size_t)3) : 0x80000000u, 0x00020000);
 
         // gather the 19 x 35 input pixels of `tile` into `dst`: pieces of 64 lanes, piece c by producer wave c % 4
-        auto fetch = [&](int tile, lds_char *dst) {
+        auto fetch = [&](const TilePos &tile, lds_char *dst) {
             int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
             if constexpr (U8) {
 #pragma unroll
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         }
         const uint32_t wr = l0a + (sub * 16 + l15) * ST_PITCH + lq * 8;      // + j * 64 * ST_PITCH + i * 32
         const bool past = sub == 3 && l15 >= 1;                  // the last group holds ONE pixel of the tile (561 = 35 * 16 + 1)
-        auto phase_a = [&](int tile, const lds_char *__restrict__ in_cur, lds_char *__restrict__ l0) {
+        auto phase_a = [&](const TilePos &tile, const lds_char *__restrict__ in_cur, lds_char *__restrict__ l0) {
             int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
             const int gy0 = iy0 + 1, gx0 = ix0 + 1;              // layer-0 coordinates of LDS pixel (0, 0)
             // a tile whose 17 x 33 layer-0 pixels all lie inside the image (every tile but the top row and the left column) needs no
@@ -256,13 +264,15 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         };
         // Every LDS region is its own __restrict__ parameter: that is what lets hipcc see that the LDS-DMA filling `dma_dst`
         // cannot alias phase A's reads, instead of waiting vmcnt(0) before the first ds_read after it.
+        TilePos pa = tile_pos((int)blockIdx.x), pf = pa;         // tiles of phase A (i + 1) and of the fetch (i + 3, or i + 2) at step i
         auto produce = [&](int i, lds_char *__restrict__ dma_dst, const lds_char *__restrict__ in_cur, lds_char *__restrict__ l0) {
             const int jf = i + (U8 ? 3 : 2);                     // tile whose input is fetched during this step
-            if (jf < nt) fetch(tile_of(jf), dma_dst);
-            if (i + 1 >= 0 && i + 1 < nt) phase_a(tile_of(i + 1), in_cur, l0);
+            if (jf < nt) fetch(pf, dma_dst);
+            advance(pf);
+            if (i + 1 >= 0 && i + 1 < nt) { phase_a(pa, in_cur, l0); advance(pa); }
         };
         static_assert(ST_GROUPS % 12 == 0, "phase A: whole groups per producer wave, three at a time");
-        if constexpr (U8) fetch(tile_of(0), (lds_char *)raw0);
+        if constexpr (U8) { fetch(pf, (lds_char *)raw0); advance(pf); }
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
         for (int i = -2; i <= nt; ++i) {                         // (one step past the last tile: the consumers drain it there)
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 fw1[ct][t] = *(const bf16x8 *)((const bf16_t *)a.w1 + (size_t)(ct * 16 + l15) * a.Kpad1 + t * 32 + lq * 8);
         const int ctid = tid - 256;
         // raw rows of `tile` (in `raw`) -> 16-byte pixel records (3 converted channels + 5 zeros) in `pix`; pixels outside the image are zeros
-        auto convert_raw = [&](int tile, const char *__restrict__ raw, char *__restrict__ pix) {
+        auto convert_raw = [&](const TilePos &tile, const char *__restrict__ raw, char *__restrict__ pix) {
             int n, iy0, ix0; tile_origin(tile, n, iy0, ix0);
 #pragma unroll
             for (int j = 0; j < (ST_INPIX + 255) / 256; ++j) {
@@ -318,12 +328,11 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         char *const lrow = lo + (2 * sub) * ST_TW * ST_OPITCH;           // this wave's 32 staged pixels
         char *const lrow2 = lo2 + (2 * sub) * ST_TW * ST_O2PITCH;
         int pn = 0, poy0 = 0, pox0 = 0;                                  // image and origin (this wave's rows) of the previous tile
+        TilePos pi = tile_pos((int)blockIdx.x), pc = pi;         // tile i (from step 0 on) and tile i + 2, the one converted at step i
         auto consume_p = [&](int i, const char *__restrict__ l0, const char *__restrict__ raw, char *__restrict__ pix, char *__restrict__ lr, char *__restrict__ lr2,
                              const char *__restrict__ lw2_) {
             const bool pv = i >= 1;                                      // there is a previous tile whose rows are staged
-            const int tile = tile_of(i < nt ? i : nt - 1);               // (the step after the last tile only drains: its phase B result is not stored)
-            const int n = tile / per_img, tr = tile - n * per_img;
-            const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+            const int n = pi.n, ty = pi.ty, tx = pi.tx;                  // (the step after the last tile only drains: its phase B result is never stored)
             // ---- previous tile: buffer offsets of its 4 + 2 store pieces (formed where they are used: six registers less across the taps) ----
             auto piece_off = [&](int it) {
                 const int c = lane + it * 64, px = c >> 3, chunk = c & 7;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
             };
             // uint8 conversion of tile i+2: geometry
             int cn = 0, ciy0 = 0, cix0 = 0; const bool cv = U8 && i + 2 < nt;
-            if (cv) tile_origin(tile_of(i + 2), cn, ciy0, cix0);
+            if (cv) tile_origin(pc, cn, ciy0, cix0);
             auto convert_round = [&](int j) {
                 const int p = ctid + j * 256;
                 const int ry = (p * 1873) >> 16, rxx = p - ry * ST_IW;           // p / 35
@@ -419,8 +428,9 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
         for (int i = -2; i <= nt; ++i) {
-            if (i >= 0) { if (i & 1) consume_p(i, l01, raw1, pix1, lrow, lrow2, lw2); else consume_p(i, l00, raw0, pix0, lrow, lrow2, lw2); }
-            else if constexpr (U8) { if (i + 2 < nt) { if (i & 1) convert_raw(tile_of(i + 2), raw1, pix1); else convert_raw(tile_of(i + 2), raw0, pix0); } }
+            if (i >= 0) { if (i & 1) consume_p(i, l01, raw1, pix1, lrow, lrow2, lw2); else consume_p(i, l00, raw0, pix0, lrow, lrow2, lw2); advance(pi); }
+            else if constexpr (U8) { if (i + 2 < nt) { if (i & 1) convert_raw(pc, raw1, pix1); else convert_raw(pc, raw0, pix0); } }
+            advance(pc);
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the records are written, the layer-0 tile is read
             __builtin_amdgcn_s_barrier();
         }
