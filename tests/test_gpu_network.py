@@ -445,10 +445,12 @@ def test_stem_and_halo_kernels_at_full_size_vs_oracle(hiplib):
     assert np.array_equal(det, det_layers)
 
 
-def test_fused_1x1_tail_halo_forms_full_size(hiplib):
+def test_fused_1x1_tail_halo_forms_full_size(hiplib, monkeypatch):
     """The same at 416 x 416, where the free-running halo forms apply: 256-channel producers under f176c256 (cfg 40), 128-channel
     producers (the 104 x 104 stage) under f176c128 (cfg 41, four tail channel tiles over eight waves), against the plan that
-    materialises every layer."""
+    materialises every layer.  (YOLO_NO_RESBLOCK: the production plan runs the 104 x 104 stage as fused residual blocks, conv_block.hip,
+    which leaves no 128-channel producer for a tail; this test is about the tail form.)"""
+    monkeypatch.setenv("YOLO_NO_RESBLOCK", "1")
     txt = IO.cfg_text("yolov3")
     secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=6)
     img = np.random.default_rng(10).integers(0, 256, (1, 416, 416, 3), dtype=np.uint8)

@@ -131,6 +131,17 @@ struct HaloArgs {
 };
 bool conv_halo_ok(const HaloArgs &a);
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s);
+// fused residual block x + act2(conv3x3(act1(conv1x1(x)))), 128 -> 64 -> 128 channels, 16-bit storage (conv_block.hip)
+struct BlockArgs {
+    const void *x; int x_stride;              // [N,H,W,>=128]: input of the 1x1 and source of the shortcut
+    const void *w1; const float *b1; int Kpad1, act1;         // 1x1: [64 pad][Kpad1], k = ci
+    const void *w2; const float *b2; int Kpad2, act2;         // 3x3: [128 pad][Kpad2], k = tap*64 + ci
+    void *out; int out_stride;                // [N,H,W,>=128]
+    int N, H, W, C, Cmid;
+    int dt;                                   // DT_BF16 or DT_F16
+};
+bool conv_resblock_ok(const BlockArgs &a);
+hipError_t launch_conv_resblock(const BlockArgs &a, hipStream_t s);
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 

@@ -44,6 +44,7 @@ struct Layer {
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
     float *d_obj = nullptr;              // ... feeding a [yolo] layer (bf16 / fp8 networks): compact plane of its objectness logits [max_batch * H * W][anchors]
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
+    bool blk_skip = false, blk = false;     // fused residual block (conv_block.hip): this 1x1 conv is computed inside the launch of the 3x3 conv that follows / this 3x3 conv launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one
     // [connected] (YOLOv1's fully connected head, V1/YOLO_V1_Inference.py:196-206; DN/connected_layer.c:151): a 1x1 conv over the
@@ -392,19 +393,29 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64)
                 L.halo = true;
         }
+    // fused residual block (conv_block.hip): a 1x1 conv 128 -> 64 read only by the 3x3 conv 64 -> 128 that follows, whose folded shortcut
+    // source is the 1x1's own input, on a grid that is whole 13 x 13 blocks (darknet-53's 104 x 104 stage at 416 x 416)
+    if (c->half_like() && !c->keep_layers && !getenv("YOLO_NO_RESBLOCK"))
+        for (int i = 1; i + 1 < NL; ++i) {
+            Layer &A = c->layers[i], &B = c->layers[i + 1];
+            if (A.type == L_CONV && B.type == L_CONV && !A.fc && !B.fc && !A.head && !B.head && uses[i] == 1 && B.in[0] == i && A.in[0] >= 0 &&
+                A.size == 1 && A.stride == 1 && A.pad == 0 && A.cin == 128 && A.filters == 64 && A.residual_from < -1 &&
+                B.size == 3 && B.stride == 1 && B.pad == 1 && B.cin == 64 && B.filters == 128 && B.residual_from == A.in[0] &&
+                B.H % 13 == 0 && B.W % 13 == 0 && A.in_dt == B.in_dt && (A.in_dt == DT_BF16 || A.in_dt == DT_F16) && A.store_dt == A.in_dt && B.store_dt == A.in_dt) { A.blk_skip = true; B.blk = true; }
+        }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
     if ((c->half_like() || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
-            if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || (P.filters != 128 && P.filters != 256)) continue;
+            if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || P.blk || (P.filters != 128 && P.filters != 256)) continue;
             int o = i;
             if (P.residual_from >= -1) o = i + 1;            // its shortcut was folded into it: consumers read layer i+1
             const int j = o + 1;
             if (j >= NL) continue;
             Layer &T = c->layers[j];
             if (T.type == L_CONV && !T.fc && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
-                T.residual_from < -1 && !T.stem_tail && T.in_dt == P.in_dt) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
+                T.residual_from < -1 && !T.stem_tail && !T.blk_skip && T.in_dt == P.in_dt) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
         }
     }
     // storage assignment: st_of[i] = storage holding layer i's output
@@ -559,6 +570,9 @@ int allocate(yolo_ctx *c)
     return YOLO_OK;
 }
 
+// layers whose kernel is fixed by a fusion (nothing for the tile tuner to choose)
+static bool fixed_kernel(const Layer &L) { return L.stem || L.stem_skip || L.stem_tail || L.halo || L.blk || L.blk_skip; }
+
 ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
 {
     ConvArgs a; memset(&a, 0, sizeof a);
@@ -613,6 +627,20 @@ int run_layer(yolo_ctx *c, int i, int n)
             t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros; t.dt = c->act_dt();
             HIPCK(c, launch_conv_stem(t, s));
             break;
+        }
+        if (L.blk_skip || L.blk) {
+            // fused residual block: the 1x1 (blk_skip) is computed inside the 3x3's launch; were the batch window ever beyond the
+            // kernel's 32-bit offsets, both run as ordinary layers
+            const Layer &A = L.blk ? c->layers[i - 1] : L, &B = L.blk ? L : c->layers[i + 1];
+            const TView x = view_of(c, A.in[0]);
+            BlockArgs b; memset(&b, 0, sizeof b);
+            b.x = x.ptr; b.x_stride = x.stride; b.w1 = A.d_w; b.b1 = A.d_b; b.Kpad1 = A.kpad; b.act1 = A.act;
+            b.w2 = B.d_w; b.b2 = B.d_b; b.Kpad2 = B.kpad; b.act2 = B.act; b.out = B.out.ptr; b.out_stride = B.out.stride;
+            b.N = n; b.H = B.H; b.W = B.W; b.C = B.filters; b.Cmid = A.filters; b.dt = B.in_dt;
+            if (conv_resblock_ok(b)) {
+                if (L.blk) HIPCK(c, launch_conv_resblock(b, s));
+                break;
+            }
         }
         ConvArgs a = conv_args(c, L, n);
         if (L.tail_on && !a.w2) return fail(c, YOLO_ERR_STATE, "layer %d: the plan folds the 1x1 conv %d into this layer, but its filters are not available in the producer's operand type", i, L.tail_layer);
@@ -1503,7 +1531,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
-        if (L.stem || L.stem_skip || L.stem_tail || L.halo) return false;                     // fused stem: nothing to choose
+        if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
@@ -1511,7 +1539,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     };
     for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail && !c->layers[i].halo) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
@@ -1527,7 +1555,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         // a configuration a layer cannot launch (LDS / 2 GiB window) must not abort the pass: probe once
         for (int i = 0; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type != L_CONV || L.tile_cfg != cfg || L.stem || L.stem_skip || L.stem_tail || L.halo) continue;
+            if (L.type != L_CONV || L.tile_cfg != cfg || fixed_kernel(L)) continue;
             ConvArgs a = conv_args(c, L, n);
             hipError_t e = a.in_dt == DT_FP8 ? launch_conv_fp8(a, cfg, c->stream) : launch_conv_bf16(a, cfg, c->stream);
             if (e != hipSuccess) { (void)hipGetLastError(); L.tile_cfg = fallback[i]; }
@@ -1535,17 +1563,17 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         int r = yolo_time_layers(c, n, iters, ms.data()); if (r) return r;
         for (int i = 0; i < NL; ++i) {
             const Layer &L = c->layers[i];
-            if (L.type == L_CONV && L.tile_cfg == cfg && !L.stem && !L.stem_skip && !L.stem_tail && !L.halo) score[shape_key(L)][cfg] += ms[i];
+            if (L.type == L_CONV && L.tile_cfg == cfg && !fixed_kernel(L)) score[shape_key(L)][cfg] += ms[i];
         }
         if (getenv("YOLO_TUNE_VERBOSE")) {
             std::map<std::string, double> seen;
-            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !c->layers[i].stem && !c->layers[i].stem_skip && !c->layers[i].stem_tail && !c->layers[i].halo) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
+            for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && c->layers[i].tile_cfg == cfg && !fixed_kernel(c->layers[i])) seen[shape_key(c->layers[i])] = score[shape_key(c->layers[i])][cfg];
             for (auto &kv : seen) fprintf(stderr, "tune %s cfg %d %-16s %.4f ms (sum over the layers of this shape, in situ)\n", kv.first.c_str(), cfg, conv_cfg_name(cfg), kv.second);
         }
     }
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type != L_CONV || L.stem || L.stem_skip || L.stem_tail || L.halo) continue;
+        if (L.type != L_CONV || fixed_kernel(L)) continue;
         auto it = score.find(shape_key(L));
         int best = fallback[i]; double bt = 1e30;
         if (it != score.end()) for (auto &kv : it->second) if (kv.second < bt) { bt = kv.second; best = kv.first; }
