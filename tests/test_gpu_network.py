@@ -507,3 +507,23 @@ def test_halo_forms_on_the_other_topologies_full_size(hiplib, cfg):
     assert np.array_equal(eng.forward(img), want)
     eng.close()
 
+
+
+@pytest.mark.parametrize("dtype_name,size,batch", [("bf16", 416, 3), ("fp16", 416, 2), ("bf16", 208, 2)])
+def test_fused_residual_block_equals_the_two_layers(hiplib, monkeypatch, dtype_name, size, batch):
+    """conv_block.hip (1x1 128 -> 64, 3x3 64 -> 128 and the shortcut of darknet-53's 128-channel stage in one launch, whenever that stage's
+    grid is whole 13 x 13 blocks: 104 x 104 at 416, 52 x 52 at 208) against the same engine with the block run as its two conv launches:
+    decoded tensors bit for bit -- every block touches an image border at 208 (4 x 4 blocks), interior and border blocks mix at 416."""
+    dtype = {"bf16": hiplib.BF16, "fp16": hiplib.FP16}[dtype_name]
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=21)
+    img = np.random.default_rng(22).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=batch, dtype=dtype)
+    eng.set_weights(flat); got = eng.forward(img); fused_bytes = eng.conv_bytes(batch); eng.close()
+    monkeypatch.setenv("YOLO_NO_RESBLOCK", "1")
+    ref = hiplib.Engine(txt, max_batch=batch, dtype=dtype)
+    ref.set_weights(flat); want = ref.forward(img); plain_bytes = ref.conv_bytes(batch); ref.close()
+    # the fused plan really ran: two blocks, each without the 64-channel tensor written once and read once
+    g = size // 4
+    assert plain_bytes - fused_bytes == 2 * 2 * batch * g * g * 64 * 2
+    assert np.isfinite(got).all() and np.array_equal(got, want)

@@ -3,21 +3,28 @@
 // Run layer by layer the block moves 352 MB at 416 x 416 x 32 (the 1x1 reads x and writes its 44 MB output, the 3x3 reads that back nine
 // taps deep, reads x again as the shortcut and writes y) for 57 GFLOP: both launches sit on the memory system (29 + 63 us).  Here a
 // workgroup owns one 13 x 13 block of output pixels at a time: the 15 x 15 x 128 halo tile of x comes into LDS by LDS-DMA (once, one block
-// ahead), the 1x1 turns it into the 15 x 15 x 64 tile the 3x3 needs -- bf16 values exactly as the unfused layer would have stored them,
-// zeros where the 3x3 pads -- and the 3x3 contracts that tile with filters held in REGISTERS: a workgroup is four waves, one per SIMD, so a
-// wave may keep 512 registers, 144 of them the 32 output channels x 576 K of its filter slice for the life of the (persistent) workgroup.
-// The K loop then has no filter traffic at all; its only LDS traffic is the 11 pixel fragments per K-step that feed 22 MFMAs.  HBM sees x
-// once (plus the 43 KB shortcut re-read of a block, an L2 hit) and y once: 176 MB.
+// ahead), the 1x1 turns it into the 15 x 15 x 64 tile the 3x3 needs -- values rounded exactly as the unfused layer would have stored them,
+// zeros where the 3x3 pads -- and the 3x3 contracts that tile with filters held in REGISTERS: a wave keeps the 32 output channels x 576 K
+// of its filter slice (144 registers) for the life of the persistent workgroup.  The K loop then has no filter traffic at all; its only
+// LDS traffic is the 6 pixel fragments per K-step that feed a wave's 12 MFMAs.  HBM sees x once (plus the 43 KB shortcut re-read of a
+// block, an L2 hit) and y once: 176 MB, and the 1x1's tensor is never materialised.
 //
-//   stage 1  wave w takes halo-pixel sub-tiles {2w', 2w'+1} in pairs: per K-step one x fragment per sub-tile and the four 16-channel filter
-//            fragments of the 1x1 (LDS), 8 MFMAs; bias, leaky, rounding, zero outside the image; ds_write_b64 into the mid tile.
-//   stage 2  wave w = output channels 32w .. 32w+31 for all 11 pixel sub-tiles of the block (169 pixels): per tap and 32-channel half
-//            11 ds_read_b128 at precomputed addresses (the tap row and the half are immediate offsets) and 22 MFMAs.
-//   epilogue bias, leaky, rounding -> LDS -> 16-byte pieces; the shortcut pieces of x were requested from global memory before the last
-//            taps; sum rounded once more (as the separate shortcut kernel would) -> global.
-// LDS layouts are XOR-swizzled so that the 16 lanes of a fragment read fall on distinct 16-byte bank slots (x: 256-byte pixel rows, slot ^
-// (pixel & 7); mid: two 32-channel planes of 64-byte rows, slot ^ ((column >> 1) & 3)); the LDS-DMA, which can only write lane-linear
-// 1 KiB pieces, achieves the swizzle by permuting which global chunk each lane fetches.
+//   waves    8 = 4 channel groups (32 output channels of the 3x3) x 2 pixel halves (sub-tiles 0-5 / 6-10 of the block's 11)
+//   stage 1  wave w takes halo-pixel sub-tiles 2w, 2w+1: per K-step one x fragment and the four 16-channel filter fragments of the 1x1
+//            (LDS), 4 MFMAs; bias, leaky, rounding, zero outside the image; ds_write_b64 into the mid tile.
+//   stage 2  per tap and 32-channel half 6 ds_read_b128 at precomputed addresses (tap and half are immediate offsets) and 12 MFMAs,
+//            reads issued one group of two fragments ahead.  Measured at the matrix-pipe floor (27.6 us of the launch's 78).
+//   epilogue bias, leaky, rounding -> LDS -> 16-byte pieces; + the shortcut piece of x from global memory, rounded once more (as the
+//            separate shortcut kernel would) -> global.
+// LDS: the x tile has 256-byte pixel rows with the 16-byte slot XOR (pixel & 7) -- the LDS-DMA, which writes lane-linear 1 KiB pieces,
+// gets the swizzle by permuting which global chunk each lane fetches; the mid tile and the staged output have padded rows (144 / 272 B):
+// the 16 lanes of a fragment read fall on distinct bank slots and every tap is an immediate offset from one address per sub-tile.
+// Registers are the constraint (256 per wave: 144 filters + 48 accumulators leave 64): a single spilled value is ruinous, because scratch
+// accesses share vmcnt with the LDS-DMA and the stores -- every reload waits for whatever of those is in flight (measured: 78 -> 155 us
+// with four spills).
+// Same box, 416 x 416 x 32, bf16: 78 us against 26 + 59 for the two launches it replaces on a fast box, 89 against 91 on a slow one; the
+// whole step gains 0.2 %: what the memory system no longer does, stage 1, the staging and the piece loop spend in issue slots (ablation:
+// stage 1 9, DMA issue 3, piece loop 15, staging / barriers / waits 25 us).  HBM traffic of a forward falls by 350 MB (6 %).
 #include "kernels.h"
 #include <type_traits>
 
