@@ -77,8 +77,8 @@ constexpr int CB_W1PITCH = CB_C * 2 + 16;              // 1x1 filter rows in LDS
 constexpr int CB_W1_BYTES = CB_M * CB_W1PITCH;         // 17408
 constexpr int CB_OPITCH = CB_C * 2 + 16;               // staged output rows
 constexpr int CB_OUT_BYTES = CB_OSUB * 16 * CB_OPITCH; // 47872
-constexpr int CB_B1_BYTES = CB_M * 4;
-constexpr int CB_LDS = CB_X_BYTES + CB_MID_BYTES + CB_W1_BYTES + CB_B1_BYTES + CB_OUT_BYTES;      // 161536
+constexpr int CB_B1_BYTES = CB_M * 4, CB_B2_BYTES = CB_C * 4;
+constexpr int CB_LDS = CB_X_BYTES + CB_MID_BYTES + CB_W1_BYTES + CB_B1_BYTES + CB_B2_BYTES + CB_OUT_BYTES;      // 162048
 
 template <bool H16>
 __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs a)
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int wc = wave & 3, wp = wave >> 2;             // channel group (32 output channels of the 3x3), pixel half
-    char *const lx_ = smem, *const lmid_ = lx_ + CB_X_BYTES, *const lw1_ = lmid_ + CB_MID_BYTES, *const lb1_ = lw1_ + CB_W1_BYTES, *const lout_ = lb1_ + CB_B1_BYTES;
+    char *const lx_ = smem, *const lmid_ = lx_ + CB_X_BYTES, *const lw1_ = lmid_ + CB_MID_BYTES, *const lb1_ = lw1_ + CB_W1_BYTES, *const lb2_ = lb1_ + CB_B1_BYTES, *const lout_ = lb2_ + CB_B2_BYTES;
     const float slope1 = a.act1 == ACT_LEAKY ? 0.1f : 1.f, slope2 = a.act2 == ACT_LEAKY ? 0.1f : 1.f;
     const int bx = a.W / CB_B, by = a.H / CB_B, per_img = bx * by, nblocks = a.N * per_img;
     const int nt = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
         for (int ks = 0; ks < 18; ++ks)
             fw2[ct][ks] = *(const cb_bf16x8 *)((const bf16_t *)a.w2 + (size_t)(wc * 32 + ct * 16 + l15) * a.Kpad2 + ks * 32 + lq * 8);
     if (tid < CB_M) *(float *)(lb1_ + tid * 4) = a.b1[tid];
+    if (tid < CB_C) *(float *)(lb2_ + tid * 4) = a.b2[tid];
 
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0x80000000u, 0x00020000);
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, 0x80000000u, 0x00020000);
@@ -114,22 +115,19 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
     // the 15 x 15 x 128 halo tile of block `q` -> lx: 3600 16-byte pieces (225 pixels x 16), lane-linear 1 KiB per instruction; the piece at
     // LDS slot `phys` of pixel p holds global chunk phys ^ (p & 7); pixels outside the image are zero-filled by the range check
     auto fetch_x = [&](const Blk &q, cb_lds_char *dst) {
-        // (a rolled loop: hipcc tracks the targets of only a handful of LDS-DMA instructions individually; with the 15 of an unrolled fetch it
-        //  falls back to "an LDS-DMA may alias any LDS access" and waits vmcnt(0) in front of the next ds instruction)
+        // Row by row: a tile row is 15 pixels x 256 B, contiguous in global memory and in LDS; piece id = 4 * row + part covers tile pixels
+        // c = 4 * part + (lane >> 4) of that row (the 16th does not exist: those lanes stay out), chunk lane & 15 of each.  Everything but the
+        // column test and the swizzle key -- (pixel & 7) = (c - row) & 7, 15 being -1 mod 8 -- is scalar.
+        // (a rolled loop: hipcc tracks the targets of only a handful of LDS-DMA instructions individually; with the pieces of an unrolled
+        //  fetch it falls back to "an LDS-DMA may alias any LDS access" and waits vmcnt(0) in front of the next ds instruction)
+        const int cl = lane >> 4, chunk = lane & 15;
 #pragma unroll 1
-        for (int k = 0; k < (CB_TPIX * 16 / 64 + CB_NW) / CB_NW; ++k) {
-            const int c = wave + CB_NW * k;              // 1 KiB piece
-            if (c * 64 < CB_TPIX * 16) {
-                int g = c * 64 + lane;
-                asm volatile("" : "+v"(g));             // (recomputed per block: hoisted out of the block loop these per-lane constants spill)
-                const int p = g >> 4, phys = g & 15;
-                const int r = (p * 4370) >> 16;          // p / 15 for p < 240
-                const int col = p - r * CB_T;
-                const int iy = q.y0 - 1 + r, ix = q.x0 - 1 + col;
-                const bool ok = p < CB_TPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)((((q.n * a.H + iy) * a.W + ix) * a.x_stride + ((phys ^ (p & 7)) * 8)) * 2) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (cb_lds_void *)(dst + c * 1024), 16, off, 0, 0, 0);
-            }
+        for (int id = wave; id < CB_T * 4; id += CB_NW) {
+            const int r = id >> 2, c = (id & 3) * 4 + cl;
+            const int iy = q.y0 - 1 + r, ix = q.x0 - 1 + c;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((((q.n * a.H + iy) * a.W + ix) * a.x_stride + ((chunk ^ ((c - r) & 7)) * 8)) * 2) : 0x80000000u;
+            if (c < CB_T) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (cb_lds_void *)(dst + (r * CB_T + (id & 3) * 4) * 256), 16, off, 0, 0, 0);
         }
     };
 
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
     // reads -- or hipcc, which cannot tell an LDS-DMA's target from any other LDS access, waits vmcnt(0) in front of the first LDS read
     // after every fetch: the whole latency of the prefetch, exposed.  The barriers order what the parameters hide.
     auto block = [&](int it, const cb_lds_char *__restrict__ lx, cb_lds_char *__restrict__ lx_dma, cb_lds_char *__restrict__ lmid, const cb_lds_char *__restrict__ mid_rd,
-                     const cb_lds_char *__restrict__ lw1, const cb_lds_char *__restrict__ lb1, cb_lds_char *__restrict__ lout) {
+                     const cb_lds_char *__restrict__ lw1, const cb_lds_char *__restrict__ lb1, const cb_lds_char *__restrict__ lb2, cb_lds_char *__restrict__ lout) {
         const Blk q = blk_of(it);
         // this block's halo tile has landed (first pass: and the 1x1 filters are written): the vector-memory queue is in order, and behind the
         // tile's LDS-DMA this thread issued the previous block's 6 shortcut loads (consumed since) and 6 stores, which may still be in flight
@@ -170,16 +168,25 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
             int p0 = (2 * u) * 16 + l15;
             asm volatile("" : "+v"(p0));
             const int p1 = p0 + 16;
+            // the fragments of K-step kk + 1 (two of pixels, four of filters) are requested ahead of the MFMAs of K-step kk
+            cb_bf16x8 xf[2][2], wf[2][4];
+            auto frags = [&](int kk) {
+                xf[kk & 1][0] = *(lds_frag_p)(lx + p0 * 256 + (((kk * 4 + lq) ^ (p0 & 7)) << 4));
+                xf[kk & 1][1] = *(lds_frag_p)(lx + p1 * 256 + (((kk * 4 + lq) ^ (p1 & 7)) << 4));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) wf[kk & 1][ct] = *(lds_frag_p)(lw1 + (ct * 16 + l15) * CB_W1PITCH + (kk * 4 + lq) * 16);
+            };
+            frags(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const cb_bf16x8 x0 = *(lds_frag_p)(lx + p0 * 256 + (((kk * 4 + lq) ^ (p0 & 7)) << 4));
-                const cb_bf16x8 x1 = *(lds_frag_p)(lx + p1 * 256 + (((kk * 4 + lq) ^ (p1 & 7)) << 4));
+                if (kk + 1 < 4) frags(kk + 1);
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    const cb_bf16x8 w = *(lds_frag_p)(lw1 + (ct * 16 + l15) * CB_W1PITCH + (kk * 4 + lq) * 16);
-                    acc[0][ct] = cb_mma<H16>(w, x0, acc[0][ct]);
-                    acc[1][ct] = cb_mma<H16>(w, x1, acc[1][ct]);
+                    acc[0][ct] = cb_mma<H16>(wf[kk & 1][ct], xf[kk & 1][0], acc[0][ct]);
+                    acc[1][ct] = cb_mma<H16>(wf[kk & 1][ct], xf[kk & 1][1], acc[1][ct]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -227,16 +234,17 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
                 __builtin_amdgcn_sched_barrier(0);
             }
         // ================= epilogue =================
-        cb_f32x4 b2v[2];
+        // bias, activation, rounding -> this wave's part of the staged tile, one channel tile at a time: the shortcut pieces of this thread
+        // (x at the pixels and channels it stores below) are requested in between, as soon as half the accumulators are dead -- their
+        // latency runs under the second half and the barrier
+        auto stage_out = [&](int ct) {
+            const cb_f32x4 bv = *(const __attribute__((address_space(3))) cb_f32x4 *)(lb2 + (wc * 32 + ct * 16 + lq * 4) * 4);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) b2v[ct] = *(const cb_f32x4 *)(a.b2 + wc * 32 + ct * 16 + lq * 4);
-#pragma unroll
-        for (int j = 0; j < CB_NJ; ++j)
-            if (wp * CB_NJ + j < CB_OSUB)                    // (wave-uniform: the second half has one idle slot)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    *(__attribute__((address_space(3))) uint2 *)(lout + ((wp * CB_NJ + j) * 16 + l15) * CB_OPITCH + (wc * 32 + ct * 16 + lq * 4) * 2) = cb_epi<H16>(acc2[ct][j], b2v[ct], slope2);
-        // the shortcut pieces of this thread (x at the pixels and channels it stores below): requested now that the accumulators are dead, they arrive across the barrier
+            for (int j = 0; j < CB_NJ; ++j)
+                if (wp * CB_NJ + j < CB_OSUB)                // (wave-uniform: the second half has one idle slot)
+                    *(__attribute__((address_space(3))) uint2 *)(lout + ((wp * CB_NJ + j) * 16 + l15) * CB_OPITCH + (wc * 32 + ct * 16 + lq * 4) * 2) = cb_epi<H16>(acc2[ct][j], bv, slope2);
+        };
+        stage_out(0);
         constexpr int NPIECE = (CB_OPIX * 16 + 64 * CB_NW - 1) / (64 * CB_NW);
         cb_u32x4 rsv[NPIECE];
 #pragma unroll
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
             const unsigned pix = (unsigned)((q.n * a.H + q.y0 + oy) * a.W + q.x0 + ox);
             rsv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, px < CB_OPIX ? (pix * a.x_stride + piece * 8) * 2 : 0x80000000u, 0, 0);
         }
+        stage_out(1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();                    // staged tile complete (and every wave is done with the mid tile)
         // 169 pixels x 16 pieces of 16 bytes: piece g of thread tid + 256 k; the shortcut is x at the same pixel and channels
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
     };
     if (nt > 0) fetch_x(blk_of(0), (cb_lds_char *)lx_);
     __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the first halo tile has landed, the 1x1 filters are written
-    for (int it = 0; it < nt; ++it) block(it, (const cb_lds_char *)lx_, (cb_lds_char *)lx_, (cb_lds_char *)lmid_, (const cb_lds_char *)(uintptr_t)0, (const cb_lds_char *)lw1_, (const cb_lds_char *)lb1_, (cb_lds_char *)lout_);
+    for (int it = 0; it < nt; ++it) block(it, (const cb_lds_char *)lx_, (cb_lds_char *)lx_, (cb_lds_char *)lmid_, (const cb_lds_char *)(uintptr_t)0, (const cb_lds_char *)lw1_, (const cb_lds_char *)lb1_, (const cb_lds_char *)lb2_, (cb_lds_char *)lout_);
 #endif
 }
 
