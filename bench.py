@@ -94,7 +94,11 @@ def main():
     flat = IO.synth_weights(secs, seed=0)
     B, G = args.batch, world
     max_out = 20
-    stream = torch.cuda.current_stream(dev)
+    # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it): on the legacy NULL stream -- torch's
+    # default -- hipGraphLaunch keeps the host until the previous replay has finished (measured: 2.67 ms of host time per replay against
+    # 21 us on a created stream, tools/probe/graph_host.py), which puts the whole submission latency between consecutive steps
+    stream = torch.cuda.current_stream(dev) if os.environ.get("BENCH_NULL_STREAM") else torch.cuda.Stream(dev)      # (the variable: for the A/B only)
+    torch.cuda.set_stream(stream)
     mixed = args.dtype == "mixed"
     fp8 = args.dtype == "fp8" or mixed
     fp32 = args.dtype == "fp32"

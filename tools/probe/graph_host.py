@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from yolo_tensorflow_amd import hip, darknet_io as IO
 B = 32
 txt = IO.cfg_text("yolov3"); secs = IO.parse_cfg(txt)
+if os.environ.get("SIDE_STREAM"):
+    torch.cuda.set_stream(torch.cuda.Stream())
 eng = hip.Engine(txt, max_batch=B, stream=torch.cuda.current_stream().cuda_stream); eng.set_weights(IO.synth_weights(secs, 0))
+print("stream handle", torch.cuda.current_stream().cuda_stream)
 eng.set_tile_configs(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_bf16.json")))["cfgs"])
 img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()
 boxes = torch.zeros((B, 20 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
