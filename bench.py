@@ -94,9 +94,11 @@ def main():
     flat = IO.synth_weights(secs, seed=0)
     B, G = args.batch, world
     max_out = 20
-    # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it): on the legacy NULL stream -- torch's
-    # default -- hipGraphLaunch keeps the host until the previous replay has finished (measured: 2.67 ms of host time per replay against
-    # 21 us on a created stream, tools/probe/graph_host.py), which puts the whole submission latency between consecutive steps
+    # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it).  torch's default stream is the legacy
+    # NULL stream, handle 0 -- which the binding cannot tell from "no stream given": the engine then runs on a stream of ITS own and
+    # hip.Engine orders every call behind torch's stream with a host-side synchronize, which on the NULL stream waits for the engine's
+    # previous replay as well (2.67 ms of host time per replay against 21 us, tools/probe/graph_host.py): the whole submission latency
+    # lands between consecutive steps.  With a created stream everything is stream-ordered and the host runs ahead.
     stream = torch.cuda.current_stream(dev) if os.environ.get("BENCH_NULL_STREAM") else torch.cuda.Stream(dev)      # (the variable: for the A/B only)
     torch.cuda.set_stream(stream)
     mixed = args.dtype == "mixed"

@@ -181,8 +181,10 @@ class Engine:
     def _order_after_producer(self, *tensors):
         """Stream ordering for device tensors.  An engine created with stream=None runs on a stream of its own, which
         nothing orders against the torch stream that produced `tensors`: wait (on the host) for that stream first.  The
-        engine's own device outputs are valid after `synchronize()`.  With an explicit stream (e.g.
-        torch.cuda.current_stream().cuda_stream, what bench.py passes) everything is stream-ordered and nothing is waited for."""
+        engine's own device outputs are valid after `synchronize()`.  With an explicit stream (the `.cuda_stream` of a torch.cuda.Stream
+        made current, what bench.py passes) everything is stream-ordered and nothing is waited for.  torch's DEFAULT stream has handle 0,
+        which is "no stream given" at this boundary: such a caller gets the engine's own stream and this host-side wait -- which, on
+        the legacy NULL stream, also waits for the engine's previous call (a detect step then costs its full device time on the host)."""
         if not self._own_stream:
             return
         for t in tensors:
