@@ -94,11 +94,12 @@ def main():
     flat = IO.synth_weights(secs, seed=0)
     B, G = args.batch, world
     max_out = 20
-    # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it).  torch's default stream is the legacy
-    # NULL stream, handle 0 -- which the binding cannot tell from "no stream given": the engine then runs on a stream of ITS own and
-    # hip.Engine orders every call behind torch's stream with a host-side synchronize, which on the NULL stream waits for the engine's
-    # previous replay as well (2.67 ms of host time per replay against 21 us, tools/probe/graph_host.py): the whole submission latency
-    # lands between consecutive steps.  With a created stream everything is stream-ordered and the host runs ahead.
+    # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it): a created stream can be captured, so
+    # the step replays as one HIP graph.  (torch's default stream is the legacy NULL stream, handle 0: hip.Engine passes it on as
+    # hipStreamLegacy -- stream-ordered too, but not capturable, the step is then launched eagerly, BENCH_NULL_STREAM=1.  Until that
+    # mapping existed, handle 0 read as "no stream given" at the boundary and the wrapper's host-side wait for torch's stream, which on
+    # the NULL stream also waits for the engine's own previous replay, put the whole submission latency between consecutive steps:
+    # 2.67 ms of host time per step against 21 us, same-box 2.720 -> 2.665 ms per step.)
     stream = torch.cuda.current_stream(dev) if os.environ.get("BENCH_NULL_STREAM") else torch.cuda.Stream(dev)      # (the variable: for the A/B only)
     torch.cuda.set_stream(stream)
     mixed = args.dtype == "mixed"

@@ -130,6 +130,19 @@ def _op_check(rc, what):
         raise YoloError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
 
+HIP_STREAM_LEGACY = 1     # hipStreamLegacy: the explicit handle of the legacy NULL stream (hip_runtime_api.h)
+
+
+def _stream_handle(stream):
+    """None: the engine creates a stream of its own.  An integer handle: the caller's stream -- and a handle of 0, which is what
+    torch.cuda.current_stream().cuda_stream reads on torch's DEFAULT stream, means that stream, not "none": it is passed on as
+    hipStreamLegacy, so that everything stays stream-ordered (NULL at the C boundary would mean "create one").  The legacy stream cannot
+    be captured: detect_graph then launches the step eagerly (same device time, ~0.17 ms of host time per step)."""
+    if stream is None:
+        return None
+    return HIP_STREAM_LEGACY if int(stream) == 0 else int(stream)
+
+
 class Engine:
     """One planned network on one GPU (a `yolo_ctx`)."""
 
@@ -137,6 +150,7 @@ class Engine:
                  keep_layers=False, stream=None):
         self.lib = load_library()
         self._cfg_bytes = cfg_text.encode()
+        stream = _stream_handle(stream)
         conf = _Config(C.sizeof(_Config), self._cfg_bytes, max_batch, dtype, semantics, decode, device,
                        1 if keep_layers else 0, C.c_void_p(stream) if stream else None)
         err = C.create_string_buffer(512)
@@ -158,6 +172,7 @@ class Engine:
         """Load an export artifact written by `export` (cfg + run configuration + packed parameters + tile plan)."""
         self = cls.__new__(cls)
         self.lib = load_library()
+        stream = _stream_handle(stream)
         err = C.create_string_buffer(512)
         self.ctx = self.lib.yolo_create_from_file(os.fsencode(path), max_batch, device, C.c_void_p(stream) if stream else None,
                                                   1 if keep_layers else 0, err, 512)
@@ -182,9 +197,8 @@ class Engine:
         """Stream ordering for device tensors.  An engine created with stream=None runs on a stream of its own, which
         nothing orders against the torch stream that produced `tensors`: wait (on the host) for that stream first.  The
         engine's own device outputs are valid after `synchronize()`.  With an explicit stream (the `.cuda_stream` of a torch.cuda.Stream
-        made current, what bench.py passes) everything is stream-ordered and nothing is waited for.  torch's DEFAULT stream has handle 0,
-        which is "no stream given" at this boundary: such a caller gets the engine's own stream and this host-side wait -- which, on
-        the legacy NULL stream, also waits for the engine's previous call (a detect step then costs its full device time on the host)."""
+        made current, what bench.py passes; or torch's default stream, handle 0, passed on as hipStreamLegacy) everything is
+        stream-ordered and nothing is waited for."""
         if not self._own_stream:
             return
         for t in tensors:
