@@ -278,3 +278,30 @@ def test_postprocess_rows_and_graph_replay_state(hiplib):
     with pytest.raises(hiplib.YoloError, match="lower threshold"):
         eng.postprocess(2, score_thr=0.1, nms_mode=hiplib.NMS_TF)
     eng.close()
+
+
+def test_torch_default_stream_is_passed_on_as_the_legacy_stream(hiplib):
+    """torch's default stream reads cuda_stream == 0, which at the C boundary would mean "create a stream": hip.Engine passes it on as
+    hipStreamLegacy instead, so the engine's launches are ordered on the caller's stream and nothing is waited for on the host.  The legacy
+    stream cannot be captured: detect_graph falls back to eager launches -- same records as an engine on a created stream, whose step
+    replays as a graph."""
+    import torch
+    assert torch.cuda.current_stream().cuda_stream == 0
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 160)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=2)
+    img = torch.from_numpy(np.random.default_rng(8).integers(0, 256, (2, 160, 160, 3), dtype=np.uint8)).cuda()
+    out = []
+    side = torch.cuda.Stream()
+    for stream in (torch.cuda.current_stream(), side):
+        with torch.cuda.stream(stream):
+            eng = hiplib.Engine(txt, max_batch=2, stream=stream.cuda_stream)
+            assert not eng._own_stream
+            eng.set_weights(flat)
+            boxes = torch.zeros((2, 25 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((2,), dtype=torch.int32, device="cuda")
+            for _ in range(4):                                    # eager, capture (or its refusal), replays
+                eng.detect_graph(img, boxes, counts, score_thr=0.3, iou_thr=0.45, max_out=25)
+            stream.synchronize()
+            out.append((boxes.cpu().numpy().copy(), counts.cpu().numpy().copy()))
+            eng.close()
+    assert out[0][1].sum() > 4
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
