@@ -40,10 +40,8 @@ typedef __attribute__((address_space(3))) char cb_lds_char;
 
 template <bool H16> __device__ __forceinline__ uint32_t cb_pk(float lo, float hi)
 {
-    if constexpr (H16) {
-        lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f); hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(cb_f32x2{lo, hi}, cb_f16x2));
-    } else return __builtin_bit_cast(uint32_t, __builtin_convertvector(cb_f32x2{lo, hi}, cb_bf16x2));
+    if constexpr (H16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(cb_f32x2{lo, hi}, cb_f16x2));      // (MODE.FP16_OVFL: an overflowing conversion saturates at +-65504)
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(cb_f32x2{lo, hi}, cb_bf16x2));
 }
 template <bool H16> __device__ __forceinline__ float cb_lo(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(cb_f16x2, w)[0]; else return __builtin_bit_cast(float, w << 16); }
 template <bool H16> __device__ __forceinline__ float cb_hi(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(cb_f16x2, w)[1]; else return __builtin_bit_cast(float, w & 0xffff0000u); }
@@ -85,6 +83,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (H16) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int wc = wave & 3, wp = wave >> 2;             // channel group (32 output channels of the 3x3), pixel half

@@ -68,6 +68,7 @@ template <int TC, bool H16 = false>
 __global__ __launch_bounds__(256) void conv_c8_3x3_direct(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (H16) fp16_saturating_mode();
     const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;

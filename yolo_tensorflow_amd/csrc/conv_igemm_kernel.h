@@ -29,12 +29,14 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 #define F16_MAX 65504.0f
+// The saturation is the hardware's: the fp16 kernels set MODE.FP16_OVFL (fp16_saturating_mode below), under which a conversion that
+// overflows yields +-65504 instead of an infinity -- two v_med3_f32 per stored pair less than clamping in fp32 first (that clamp was the
+// 3-4 % fp16 cost against bf16).
+__device__ __forceinline__ void fp16_saturating_mode() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
 template <bool H16> __device__ __forceinline__ uint32_t pack16x2(float lo, float hi)
 {
-    if constexpr (H16) {
-        lo = __builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX); hi = __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX);
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));       // RNE
-    } else return f32x2_to_bf16x2(lo, hi);
+    if constexpr (H16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));       // RNE, saturating (FP16_OVFL)
+    else return f32x2_to_bf16x2(lo, hi);
 }
 template <bool H16> __device__ __forceinline__ float unpack16_lo(uint32_t w)
 {
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     static_assert(!HALO || LAH <= 9, "a halo tile is fetched during the nine taps of the previous chunk");
     static_assert(!FREE || (HALO && NL == 0 && LB * RG == TC * 16), "free-running form: every wave fetches its own filter rows");
 
+    if constexpr (H16) fp16_saturating_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][ BP rows | BC rows ][128 B]
 
     unsigned long long t_top = 0;              // DIAG: first instruction of the wave

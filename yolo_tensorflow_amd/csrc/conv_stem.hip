@@ -30,13 +30,11 @@ typedef __bf16 st_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float st_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 st_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
-// two floats -> packed 16-bit pair (lo | hi << 16), RNE: bf16 (one v_cvt_pk_bf16_f32) or, H16, fp16 saturating at +-65504
+// two floats -> packed 16-bit pair (lo | hi << 16), RNE: bf16 (one v_cvt_pk_bf16_f32) or, H16, fp16 saturating at +-65504 (MODE.FP16_OVFL, set at the top of the H16 kernels)
 template <bool H16> __device__ __forceinline__ uint32_t stem_pk(float lo, float hi)
 {
-    if constexpr (H16) {
-        lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f); hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_f16x2));
-    } else return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_bf16x2));
+    if constexpr (H16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_f16x2));      // (the H16 kernels run with MODE.FP16_OVFL: an overflowing conversion saturates)
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(st_f32x2{lo, hi}, st_bf16x2));
 }
 template <bool H16> __device__ __forceinline__ float stem_lo(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(st_f16x2, w)[0]; else return __builtin_bit_cast(float, w << 16); }
 template <bool H16> __device__ __forceinline__ float stem_hi(uint32_t w) { if constexpr (H16) return (float)__builtin_bit_cast(st_f16x2, w)[1]; else return __builtin_bit_cast(float, w & 0xffff0000u); }
@@ -102,6 +100,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (H16) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: fp16 conversions saturate
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int sub = wave & 3;                                    // index among the four waves of this wave's role
@@ -458,6 +457,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (H16) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: fp16 conversions saturate
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     bf16x8 fw[4][9];
