@@ -375,27 +375,34 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     }
     // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
     // (the stem and halo kernels address their input with 32-bit buffer offsets: the whole-batch window must stay under 2 GiB)
-    if (c->half_like() && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
+    // (an e4m3 network whose first layers are stored in a 16-bit type -- a mixed plan, yolo_store=bf16 -- runs them through the same fused
+    //  kernels: what counts is the type of the tensors a kernel touches, not the context's)
+    const bool ctx16 = c->half_like() || c->dtype == YOLO_FP8;
+    auto is16 = [](int dt) { return dt == DT_BF16 || dt == DT_F16; };
+    if (ctx16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
         const Layer &A = c->layers[0], &B = c->layers[1];
         if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
-            A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1) {
+            A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1 &&
+            is16(A.in_dt) && A.store_dt == A.in_dt && B.in_dt == A.in_dt && B.store_dt == A.in_dt) {        // (layer 0 reads the staged image, which is kept in its operand type)
             c->layers[0].stem_skip = true; c->layers[1].stem = true;
             if (NL >= 3) {
                 const Layer &T = c->layers[2];
-                if (T.type == L_CONV && !T.fc && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1)
+                if (T.type == L_CONV && !T.fc && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1 &&
+                    T.in_dt == A.in_dt && T.store_dt == A.in_dt)
                     c->layers[2].stem_tail = true;
             }
         }
     }
-    if (c->half_like() && !getenv("YOLO_NO_HALO"))
+    if (ctx16 && !getenv("YOLO_NO_HALO"))
         for (int i = 1; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64)
+            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64 &&
+                is16(L.in_dt) && L.store_dt == L.in_dt && (L.residual_from < 0 || c->layers[L.residual_from].store_dt == L.in_dt))
                 L.halo = true;
         }
     // fused residual block (conv_block.hip): a 1x1 conv 128 -> 64 read only by the 3x3 conv 64 -> 128 that follows, whose folded shortcut
     // source is the 1x1's own input, on a grid that is whole 13 x 13 blocks (darknet-53's 104 x 104 stage at 416 x 416)
-    if (c->half_like() && !c->keep_layers && !getenv("YOLO_NO_RESBLOCK"))
+    if (ctx16 && !c->keep_layers && !getenv("YOLO_NO_RESBLOCK"))
         for (int i = 1; i + 1 < NL; ++i) {
             Layer &A = c->layers[i], &B = c->layers[i + 1];
             if (A.type == L_CONV && B.type == L_CONV && !A.fc && !B.fc && !A.head && !B.head && uses[i] == 1 && B.in[0] == i && A.in[0] >= 0 &&
@@ -624,7 +631,7 @@ int run_layer(yolo_ctx *c, int i, int n)
                 const Layer &T = c->layers[i + 1];
                 t.w2 = T.d_w; t.b2 = T.d_b; t.Kpad2 = T.kpad; t.C2 = T.filters; t.act2 = T.act; t.out2 = T.out.ptr; t.out2_stride = T.out.stride;
             }
-            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros; t.dt = c->act_dt();
+            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W; t.zeros = c->d_zeros; t.dt = L.in_dt;
             HIPCK(c, launch_conv_stem(t, s));
             break;
         }
