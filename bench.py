@@ -58,12 +58,48 @@ def cpu_baseline(cfg_txt, flat, budget_s=25.0):
             "sample": "%d x YOLOv3-416 batch-1 forward after 1 warm-up, median %.3f s/image" % (len(times), med)}
 
 
+def parity(eng, cfg_txt, flat, imgs_u8, size, thr=0.5, margin=1e-2):
+    """Boxes of the timed engine (its dtype, its tile plan) against the fp32 oracle (TF semantics) on the first images of the timed batch:
+    over every oracle candidate whose score clears `thr` by more than `margin` (a candidate inside the band may legitimately flip),
+    min IoU and max |dscore|.  The checker runs on the host outside the timed region; tests/test_gpu_tuned.py asserts the same measure
+    over all 32 images."""
+    from oracle import yolo_ref as R
+    t0 = time.time()
+    det = eng.forward(imgs_u8)
+    osecs = R.parse_cfg(cfg_txt.replace("yolo_store=bf16\n", "").replace("yolo_store=fp8\n", "")); params = R.unflatten_weights(flat, osecs)
+    miou, mds, cnt, lost = 1.0, 0.0, 0, 0
+    for b in range(imgs_u8.shape[0]):
+        heads, _ = R.forward(osecs, params, imgs_u8[b:b + 1].astype(np.float32) / np.float32(255))
+        ref = R.yolo_v3_detections(heads, size, ratio=True)[0]
+        rb, rs, rc, ridx = R.select_threshold(ref, thr)
+        ok = rs >= thr + margin
+        if not ok.any():
+            continue
+        d = det[b][ridx[ok]]
+        sc = (d[:, 4:5] * d[:, 5:]).max(-1)
+        bx = np.stack([d[:, 0] - d[:, 2] / 2, d[:, 1] - d[:, 3] / 2, d[:, 0] + d[:, 2] / 2, d[:, 1] + d[:, 3] / 2], -1)
+        a = rb[ok]
+        ix = np.maximum(0, np.minimum(a[:, 2], bx[:, 2]) - np.maximum(a[:, 0], bx[:, 0])); iy = np.maximum(0, np.minimum(a[:, 3], bx[:, 3]) - np.maximum(a[:, 1], bx[:, 1]))
+        inter = ix * iy
+        iou = inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1]) - inter + 1e-12)
+        miou = min(miou, float(iou.min())); mds = max(mds, float(np.abs(rs[ok] - sc).max())); cnt += int(ok.sum()); lost += int((sc <= thr).sum())
+    return {"min_iou": round(miou, 5), "max_dscore": round(mds, 5), "candidates": cnt, "lost": lost, "images": int(imgs_u8.shape[0]),
+            "reference": "fp32 oracle (oracle/yolo_ref.py, TF semantics)", "weights": "seeded synthetic darknet stream (seed 0), benign batch-norm statistics",
+            "threshold": thr, "margin": margin, "seconds": round(time.time() - t0, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (weak scaling: the global batch grows with --gpus)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: a fixed global batch split contiguously over the ranks (earlier ranks take the remainder); "
+                         "0 = off (weak scaling, --batch images per GPU).  BASELINE.json's 'batch=32, 1/2/4/8x' read as one batch of 32 is "
+                         "--global-batch 32: 32 / 16 / 8 / 4 images per GPU")
+    ap.add_argument("--config4", action="store_true", help="BASELINE.json config 4: 608x608, global batch 64 sharded over the ranks (= --size 608 --global-batch 64)")
+    ap.add_argument("--parity-images", type=int, default=2, help="images of the timed batch whose boxes are compared with the fp32 oracle for the `parity` field (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -74,6 +110,8 @@ def main():
                          "MFMA rate, 11-bit significand); mixed is config 5 with the layers named in tuned/yolov3_*_mixed.json kept in bf16 "
                          "(the plan that brings the e4m3 configuration's boxes back to IoU >= 0.97) (each reported as a separate line)")
     args = ap.parse_args()
+    if args.config4:
+        args.size, args.global_batch = 608, args.global_batch or 64
 
     import torch
     import torch.distributed as dist
@@ -92,7 +130,17 @@ def main():
     cfg_txt = IO.cfg_text("yolov3") if args.size == 416 else IO.with_input_size(IO.cfg_text("yolov3"), args.size)
     secs = IO.parse_cfg(cfg_txt)
     flat = IO.synth_weights(secs, seed=0)
-    B, G = args.batch, world
+    G = world
+    strong = args.global_batch > 0
+    if strong:      # fixed global batch: this rank's share (ragged when G does not divide it); B = the largest share = every rank's buffer size
+        GB = args.global_batch
+        if GB < G:
+            raise SystemExit("--global-batch %d < %d ranks" % (GB, G))
+        lo, hi = ydist.shard_bounds(GB, G, rank)
+        B = -(-GB // G)
+    else:
+        B = args.batch; GB = B * G; lo, hi = ydist.shard_bounds(GB, G, rank)
+    n_local = hi - lo
     max_out = 20
     # A stream of our own, made torch's current one (events, RCCL and the library all enqueue on it): a created stream can be captured, so
     # the step replays as one HIP graph.  (torch's default stream is the legacy NULL stream, handle 0: hip.Engine passes it on as
@@ -116,8 +164,7 @@ def main():
     eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP8 if fp8 else hip.FP32 if fp32 else hip.FP16 if fp16 else hip.BF16, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO,
                      device=local_rank, stream=stream.cuda_stream)
     eng.set_weights(flat)
-    # this rank's shard of the global batch (weak scaling: B images per GPU), resident in HBM
-    lo, hi = ydist.shard_bounds(B * G, G, rank)
+    # this rank's shard of the global batch (weak scaling: B images per GPU; strong: n_local of GB), resident in HBM
     rng = np.random.default_rng(1 + rank)
     images = torch.from_numpy(rng.integers(0, 256, (hi - lo, args.size, args.size, 3), dtype=np.uint8)).to(dev)
     # one flat record buffer per rank: [B * max_out] box records (6 x int32 each) followed by [B] counts, written in place by
@@ -149,7 +196,7 @@ def main():
     def step():
         if args.no_graph:
             eng.forward(images, want_detections=False)
-            eng.postprocess(B, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT,
+            eng.postprocess(n_local, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT,
                             boxes_out=boxes, counts_out=counts)
         else:   # same launches, replayed from a HIP graph captured on the second call
             eng.detect_graph(images, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF,
@@ -183,7 +230,7 @@ def main():
     step_ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
 
     if rank == 0:
-        total_ms, conv_ms = eng.time_forward(B, 10, conv=True)
+        total_ms, conv_ms = eng.time_forward(n_local, 10, conv=True)
         # HBM bytes per forward of the conv launches: PMC counters cannot be read in-process, so this is the committed
         # rocprofv3 measurement (tools/profile_round.sh) -- printed only when it was taken on exactly this code and tile plan
         # (source hash), null otherwise: a stale number is never reported
@@ -196,27 +243,29 @@ def main():
                     traffic = tj["conv_hbm_bytes_per_forward"]; break
             except Exception:      # noqa: BLE001
                 pass
-        flops = eng.conv_flops() * B
+        flops = eng.conv_flops() * n_local
         achieved = flops / (conv_ms * 1e-3) / 1e12
         out = {
-            "metric": "images_per_sec", "value": round(B * G * args.steps / elapsed, 2), "unit": "img/s",
+            "metric": "images_per_sec", "value": round(GB * args.steps / elapsed, 2), "unit": "img/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "YOLOv3 %dx%d batch=%d per GPU, %s: conv stack + head decode + threshold + TF-NMS%s"
-                                   % (args.size, args.size, B, "e4m3 backbone to 26x26 + bf16 13x13 stage and FPN (tuned/yolov3_%d_b%d_mixed.json), fp32 heads" % (args.size, B) if mixed else "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "exact fp32 (f32 MFMA)" if fp32 else "fp16 storage, fp32 accumulation" if fp16 else "bf16",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "YOLOv3 %dx%d %s, %s: conv stack + head decode + threshold + TF-NMS%s"
+                                   % (args.size, args.size, ("global batch=%d split over %d GPU(s), %d image(s) on rank 0" % (GB, G, n_local)) if strong else "batch=%d per GPU" % B, "e4m3 backbone to 26x26 + bf16 13x13 stage and FPN (tuned/yolov3_%d_b%d_mixed.json), fp32 heads" % (args.size, B) if mixed else "e4m3 filters and activations (scales 1), fp32 heads" if fp8 else "exact fp32 (f32 MFMA)" if fp32 else "fp16 storage, fp32 accumulation" if fp16 else "bf16",
                                       " + RCCL all-gather of box records" if G > 1 else ""),
-                       "global_batch": B * G, "input": "uint8 NHWC resident in HBM", "weights": "seeded synthetic darknet stream (seed 0)",
+                       "global_batch": GB, "input": "uint8 NHWC resident in HBM", "weights": "seeded synthetic darknet stream (seed 0)",
                        "parallelism": "dp%d" % G if G == 1 else
                                       "dp%d; the box-record all-gather of step n runs under the compute of step n+1 (dist.PipelinedGather): "
                                       "p50_ms_* are per-step compute on rank 0 and EXCLUDE the exchange, value / ms_per_step include every "
                                       "exchange (the last one is waited for inside the timed region)" % G},
-            "p50_ms_per_image": round(float(np.median(step_ms)) / B, 5),
+            "p50_ms_per_image": round(float(np.median(step_ms)) / n_local, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": "conv_igemm_f32 (every conv launch of one forward)" if fp32 else "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
+        if G == 1 and args.parity_images > 0:
+            out["parity"] = parity(eng, cfg_txt, flat, images[:min(args.parity_images, n_local)].cpu().numpy(), args.size)
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_txt, flat)
         print(json.dumps(out), flush=True)

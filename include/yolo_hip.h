@@ -211,7 +211,10 @@ int yolo_synchronize(yolo_ctx *ctx);
 int yolo_layer_output(yolo_ctx *ctx, int index, int n, float *out, size_t out_floats, int *dims_out);
 /* Times `iters` forwards of batch n on the context stream with HIP events:
  * total_ms = wall per forward; conv_ms = the conv launches' share of it (all layers minus all-but-conv, bulk-timed)
- * (events around every conv launch, separate pass).  Either may be NULL. */
+ * (events around every conv launch, separate pass).  Either may be NULL.
+ * The timing entry points (this one, yolo_time_layers, yolo_autotune) run the network on the INPUT OF THE LAST FORWARD.  When that call
+ * was given a device-resident uint8 batch, the fused first layers read the caller's buffer in place: it must still be valid here.  A
+ * timing pass over more images than that batch held reads the context's own (zero-initialised or previously staged) input instead. */
 int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *conv_ms);
 /* Per-layer kernel time (ms, averaged over iters) for batch n into ms_out[num_layers]. */
 int yolo_time_layers(yolo_ctx *ctx, int n, int iters, float *ms_out);

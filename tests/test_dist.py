@@ -131,3 +131,40 @@ def test_two_rank_pipelined_gather():
             want, cnt = _fake_boxes(100 * step + i, max_out)
             assert gc[i] == cnt and np.array_equal(gb[i].numpy(), want.view(np.int32).reshape(-1))
 
+
+
+def _strong_worker(rank, world, port, GB, max_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = -(-GB // world)
+    lo, hi = ydist.shard_bounds(GB, world, rank)
+    rec, boxes, counts = ydist.alloc_flat_records(per, max_out, "cpu")       # every rank's buffer is sized for the largest share
+    for i in range(lo, hi):                                                   # the library fills the first hi - lo images in place
+        b, cnt = _fake_boxes(i, max_out)
+        boxes[i - lo] = torch.from_numpy(b.view(np.int32).reshape(-1)); counts[i - lo] = cnt
+    g = ydist.PipelinedGather(rec); g.submit(rec)
+    gb, gc = ydist.split_flat_records_ragged(g.result(), GB, max_out)
+    q.put((rank, gb.numpy().copy(), gc.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("GB,world", [(32, 2), (7, 3)])      # bench.py --global-batch: 16 + 16; ragged 3 + 2 + 2
+def test_strong_scaling_split_of_a_fixed_global_batch(GB, world):
+    """bench.py's strong-scaling mode: a fixed global batch split contiguously, every rank exchanging a buffer sized for the largest
+    share; the gathered records come back in global image order with the short ranks' padding rows dropped."""
+    max_out = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() + 13 * world) % 2000
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, GB, max_out, q)) for r in range(world)]
+    for p in procs: p.start()
+    results = {r: (b, c) for r, b, c in (q.get(timeout=120) for _ in range(world))}
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    gb, gc = results[0]
+    assert gb.shape == (GB, max_out * 6) and gc.shape == (GB,)
+    for r in range(1, world):
+        assert np.array_equal(results[r][0], gb) and np.array_equal(results[r][1], gc)
+    for i in range(GB):
+        want, cnt = _fake_boxes(i, max_out)
+        assert gc[i] == cnt and np.array_equal(gb[i], want.view(np.int32).reshape(-1))

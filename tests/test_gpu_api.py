@@ -305,3 +305,43 @@ def test_torch_default_stream_is_passed_on_as_the_legacy_stream(hiplib):
             eng.close()
     assert out[0][1].sum() > 4
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_advice_r03_stale_uint8_pointer_and_dirty_list_counter(hiplib):
+    """ADVICE r03.  (1) After a forward that read the caller's device-resident uint8 batch in place (fused stem), a timing / autotune pass
+    over MORE images than that batch held must not read past the caller's buffer: it runs on the context's own input, and the next detect
+    is unaffected.  (2) A detect call refused for its postprocess arguments is refused BEFORE the forward runs, and a replayed detect
+    graph after such a call (or after any step that left the lean decode's list counter set) still equals the eager result -- no phantom
+    boxes from stale list entries."""
+    import torch
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 160)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=4)
+    rng = np.random.default_rng(9)
+    img1 = torch.from_numpy(rng.integers(0, 256, (1, 160, 160, 3), dtype=np.uint8)).cuda()
+    img4 = torch.from_numpy(rng.integers(0, 256, (4, 160, 160, 3), dtype=np.uint8)).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng = hiplib.Engine(txt, max_batch=4, stream=side.cuda_stream)
+        eng.set_weights(flat)
+        want = eng.detect(img4, score_thr=0.3, iou_thr=0.45, max_out=25)
+        eng.forward(img1, want_detections=False)                 # the stem now points at a ONE-image buffer
+        ms = eng.time_layers(4, 1)                               # four images: must not read 3 images past img1
+        assert ms.shape[0] == eng.num_layers and np.isfinite(ms).all()
+        t, cv = eng.time_forward(4, 1)
+        assert t > 0 and cv > 0
+        boxes = torch.zeros((4, 25 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((4,), dtype=torch.int32, device="cuda")
+        for _ in range(3):                                       # eager, capture, replay
+            eng.detect_graph(img4, boxes, counts, score_thr=0.3, iou_thr=0.45, max_out=25)
+        with pytest.raises(hiplib.YoloError, match="max_out"):   # refused before any launch
+            eng.detect(img4, score_thr=0.3, iou_thr=0.45, max_out=0)
+        with pytest.raises(hiplib.YoloError, match="nms/select"):
+            eng.detect(img4, score_thr=0.3, iou_thr=0.45, max_out=25, nms_mode=17)
+        eng.forward(img4, want_detections=False)                 # an eager pass in between (full decode: does not touch the list)
+        for _ in range(2):
+            eng.detect_graph(img4, boxes, counts, score_thr=0.3, iou_thr=0.45, max_out=25)
+        side.synchronize()
+        got_c = counts.cpu().numpy(); got = boxes.cpu().numpy().view(hiplib.BOX_DTYPE).reshape(4, 25)
+        assert got_c.sum() > 4
+        for b in range(4):
+            assert got_c[b] == len(want[b]) and np.array_equal(got[b, :got_c[b]], want[b])
+        eng.close()

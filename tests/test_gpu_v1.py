@@ -178,3 +178,54 @@ def test_local_layers_match_compiled_reference(hiplib, tmp_path):
         eng.close()
     with pytest.raises(hiplib.YoloError, match="fp8"):
         hiplib.Engine(cfg, dtype=hiplib.FP8)
+
+
+def test_local_layer_pad_channels_are_zero_and_bad_pad_is_refused(hiplib):
+    """a [local] layer whose filter count is not a multiple of 8 stores its pixel in roundup(F, 8) channels; the pad channels
+    must be written as zeros (the consumer multiplies them by zero filters: 0 * stale Inf would be NaN), and pad=1 with size != 3 is
+    refused (darknet's own output size and im2col padding disagree there, DN/local_layer.c:10-24,103)."""
+    cfg = """[net]
+height=16
+width=16
+channels=3
+[convolutional]
+filters=8
+size=3
+stride=2
+pad=1
+activation=leaky
+[local]
+filters=5
+size=3
+stride=1
+pad=1
+activation=leaky
+[convolutional]
+filters=8
+size=1
+stride=1
+activation=leaky
+[connected]
+output=%d
+activation=linear
+[detection]
+classes=2
+coords=4
+side=2
+num=1
+sqrt=1
+""" % (2 * 2 * (2 + 5))
+    secs = IO.parse_cfg(cfg); flat = IO.synth_weights(secs, seed=1)
+    x = np.random.default_rng(2).integers(0, 256, (2, 16, 16, 3), dtype=np.uint8)
+    osecs = R.parse_cfg(cfg)
+    heads, _ = R.forward(osecs, R.unflatten_weights(flat, osecs), x.astype(np.float32) / np.float32(255), semantics="darknet")
+    for rep in range(2):                     # twice: the second engine is likely to recycle the first one's buffers
+        eng = hiplib.Engine(cfg, max_batch=2, dtype=hiplib.FP32, semantics=hiplib.SEM_DARKNET)
+        eng.set_weights(flat)
+        eng.forward(x)
+        got = eng.last_layer_output(2)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, heads[0][1].reshape(2, -1), rtol=2e-4, atol=2e-5)
+        eng.close()
+    with pytest.raises(hiplib.YoloError, match="size=3"):
+        hiplib.Engine(cfg.replace("filters=5\nsize=3", "filters=5\nsize=5"), max_batch=1, dtype=hiplib.FP32)

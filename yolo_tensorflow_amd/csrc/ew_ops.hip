@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256) void k_local(const T *in, int in_stride, const
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int loc = blockIdx.x, f = blockIdx.y * 4 + wv;
-    if (f >= F) return;
+    if (f >= F) {                // channels F .. roundup(F, 8) of the stored pixel: zero, so that a consumer's zero filters never meet stale Inf / NaN
+        if (f < ((F + 7) & ~7) && lane == 0) for (int b = 0; b < n; ++b) Elt<T>::store1(out + ((size_t)b * Ho * Wo + loc) * out_stride + f, 0.f);
+        return;
+    }
     const int oy = loc / Wo, ox = loc - oy * Wo;
     const int c8n = C / 8, K8 = k * k * c8n;                      // 8-channel granules per tap / per filter row
     const T *wr = w + ((size_t)loc * F + f) * (size_t)K8 * 8;
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256) void k_local(const T *in, int in_stride, const
 hipError_t launch_local(const TView &in, const TView &out, const void *w, const float *bias, int k, int stride, int pad, int act, hipStream_t s)
 {
     if (in.c % 8 || in.dt != out.dt || in.dt == DT_FP8) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(out.h * out.w), (unsigned)((out.c + 3) / 4));
+    dim3 grid((unsigned)(out.h * out.w), (unsigned)((((out.c + 7) & ~7) + 3) / 4));
     WITH_DT(in.dt, hipLaunchKernelGGL(k_local<T>, grid, dim3(256), 0, s, (const T *)in.ptr, in.stride, (const T *)w, bias, (T *)out.ptr, out.stride,
                                       in.n, in.h, in.w, in.c, out.h, out.w, out.c, k, stride, pad, act));
     return hipGetLastError();

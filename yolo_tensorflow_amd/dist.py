@@ -136,3 +136,19 @@ def split_flat_records(rec_all, n_local, max_out):
     world = rec_all.shape[0]
     nb = n_local * max_out * RECORD_FLOATS
     return rec_all[:, :nb].reshape(world * n_local, max_out * RECORD_FLOATS), rec_all[:, nb:].reshape(world * n_local)
+
+
+def split_flat_records_ragged(rec_all, global_batch, max_out):
+    """Strong scaling (bench.py --global-batch): every rank's flat buffer is sized for per = ceil(global_batch / world) images and rank r
+    filled the first shard_bounds(global_batch, world, r) of them.  [world, flat] -> (boxes [global_batch, max_out*6], counts
+    [global_batch]) in global image order (the padding rows of the short ranks are dropped)."""
+    import torch
+    world = rec_all.shape[0]
+    per = -(-global_batch // world)
+    boxes, counts = split_flat_records(rec_all, per, max_out)
+    keep = []
+    for r in range(world):
+        lo, hi = shard_bounds(global_batch, world, r)
+        keep.append(torch.arange(r * per, r * per + (hi - lo), device=rec_all.device))
+    keep = torch.cat(keep)
+    return boxes[keep], counts[keep]

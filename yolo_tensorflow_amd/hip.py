@@ -130,6 +130,7 @@ def _op_check(rc, what):
         raise YoloError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
 
+_warned_legacy = False
 HIP_STREAM_LEGACY = 1     # hipStreamLegacy: the explicit handle of the legacy NULL stream (hip_runtime_api.h)
 
 
@@ -137,10 +138,22 @@ def _stream_handle(stream):
     """None: the engine creates a stream of its own.  An integer handle: the caller's stream -- and a handle of 0, which is what
     torch.cuda.current_stream().cuda_stream reads on torch's DEFAULT stream, means that stream, not "none": it is passed on as
     hipStreamLegacy, so that everything stays stream-ordered (NULL at the C boundary would mean "create one").  The legacy stream cannot
-    be captured: detect_graph then launches the step eagerly (same device time, ~0.17 ms of host time per step)."""
+    be captured: detect_graph then launches the step eagerly (same device time, ~0.17 ms of host time per step; a one-time
+    RuntimeWarning says so).  The legacy stream orders itself against torch's default stream and every BLOCKING stream; a tensor produced
+    on a NON-blocking side stream (torch.cuda.Stream() is one) must be ordered by the caller (event / synchronize) before it is handed
+    over -- unlike stream=None, where the engine waits on the host for the producer stream."""
     if stream is None:
         return None
-    return HIP_STREAM_LEGACY if int(stream) == 0 else int(stream)
+    if int(stream) == 0:
+        global _warned_legacy
+        if not _warned_legacy:
+            _warned_legacy = True
+            import warnings
+            warnings.warn("stream handle 0 is torch's default (legacy NULL) stream: the engine runs on hipStreamLegacy, detect_graph launches "
+                          "eagerly (the legacy stream cannot be captured) and tensors from non-blocking side streams are not ordered "
+                          "against it; pass stream=None for an engine-owned stream or a created stream's handle", RuntimeWarning, stacklevel=3)
+        return HIP_STREAM_LEGACY
+    return int(stream)
 
 
 class Engine:
