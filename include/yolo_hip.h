@@ -46,9 +46,15 @@ enum yolo_status {
 /* storage/compute type of the conv stack.  YOLO_FP8 (BASELINE config 5): OCP e4m3 filters and activations on the
  * fp8 MFMA (fp32 accumulation, heads in fp32, first conv in bf16); scheme and scales: DESIGN.md "fp8 scheme". */
 enum yolo_dtype { YOLO_BF16 = 0, YOLO_FP32 = 1, YOLO_FP8 = 2,
-                  YOLO_FP16 = 3 };  /* IEEE fp16 filters and activations on v_mfma_f32_16x16x32_f16: the bf16 configuration's kernels,
+                  YOLO_FP16 = 3,    /* IEEE fp16 filters and activations on v_mfma_f32_16x16x32_f16: the bf16 configuration's kernels,
                                      * tile plans and MFMA rate with an 11-bit significand instead of 8 (values saturate at +-65504);
                                      * what it buys in box accuracy: DESIGN.md section 4 */
+                  YOLO_FP16X2 = 4 };/* split fp16 (round 4): every filter and stored activation is a PAIR of fp16 numbers hi = f16(v),
+                                     * lo = f16(v - hi) -- 22 significant bits -- and a conv forms W_hi x_hi + W_hi x_lo + W_lo x_hi on the
+                                     * fp16 MFMA with fp32 accumulation (three products per algorithmic one, W_lo x_lo is dropped).  The
+                                     * configuration that meets north_star's IoU >= 0.999 on weights with a trained file's statistics at
+                                     * several times the exact-fp32 path's rate; no fusions (every layer is its own launch), [connected] /
+                                     * [local] layers are not served.  DESIGN.md section 3.6 */
 enum yolo_semantics { YOLO_SEM_TF = 0, YOLO_SEM_DARKNET = 1 };
 /* TF: bilinear `_upsample` (V3/yolo_v3.py:162-192) + tf.space_to_depth (V2/model_darknet19_slim.py:44);
  * DARKNET: nearest upsample (DN/blas.c:334) + reorg_cpu (DN/blas.c:9) -- lets the whole network be

@@ -323,3 +323,27 @@ def test_nms_detections_op_vs_oracle(hiplib):
     assert p.shape == (0, 3) and o.shape == (0,)
     with pytest.raises(hiplib.YoloError):
         hiplib.op_nms_detections(np.zeros((5000, 4), np.float32), np.zeros((5000, 2), np.float32), np.ones(5000, np.float32), 0.45)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8"])
+def test_halo_form_on_ragged_blocks_equals_tiled_form(hiplib, dtype):
+    """Round 4: the halo-staged 3x3 forms on sizes that are NOT multiples of 13 (608 x 608 networks: 38 = 3 * 13 - 1, 76 = 6 * 13 - 2):
+    ragged 13 x 13 blocks on the bottom / right edge, whose columns past the image are computed on zeros and never stored.  Every halo
+    configuration (barrier-per-K-step, role-split, free-running, 3 stages) is bit-identical to the tiled form, with and without the fused
+    shortcut; 19 x 19 (would compute 26 x 26) is refused."""
+    dt = {"bf16": hiplib.BF16, "fp16": hiplib.FP16, "fp8": hiplib.FP8}[dtype]
+    rng = np.random.default_rng(5)
+    cin = 128
+    for (n, h, cout) in ((3, 38, 256), (2, 76, 128), (2, 25, 128)):
+        x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+        w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((n, h, h, cout)).astype(np.float32)
+        for r in (None, res):
+            want = hiplib.op_conv2d(x, w, b, act=1, residual=r, dtype=dt, tile_cfg=16)
+            for cfg in range(36, 44):
+                got = hiplib.op_conv2d(x, w, b, act=1, residual=r, dtype=dt, tile_cfg=cfg)
+                assert np.array_equal(got, want), (dtype, h, cout, cfg, r is not None)
+    x = rng.standard_normal((1, 19, 19, cin)).astype(np.float32)
+    with pytest.raises(hiplib.YoloError, match="not applicable"):
+        hiplib.op_conv2d(x, (rng.standard_normal((3, 3, cin, 128)) * 0.05).astype(np.float32), None, dtype=dt, tile_cfg=40)

@@ -3,21 +3,29 @@
 # the PMC passes (HBM traffic, MFMA busy) on tools/prof_forward.py.  Everything lands in gpurun_out/prof_$1/;
 # tools/summarize_profile.py condenses that into $OUT/summary/, which is copied to profiles/ by hand afterwards.
 set -u
-R=${1:-r03}
+# SIZE / BATCH (default 416 / 32 = the headline workload) select another workload, e.g. SIZE=608 BATCH=8 bash tools/profile_round.sh r04_608_b8
+# (BASELINE config 4's per-GPU share): the bf16 line, its kernel trace and the PMC passes only.
+R=${1:-r04}
+export SIZE=${SIZE:-416} B=${BATCH:-32}
+W="--size $SIZE --batch $B"
 OUT=gpurun_out/prof_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
+if [ "$SIZE" = 416 ] && [ "$B" = 32 ]; then
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python3 bench.py --dtype fp8 --no-cpu-baseline > "$OUT/bench_fp8.json" 2> "$OUT/bench_fp8.err"
-python3 bench.py --dtype mixed --no-cpu-baseline > "$OUT/bench_mixed.json" 2> "$OUT/bench_mixed.err"
-python3 bench.py --dtype fp16 --no-cpu-baseline > "$OUT/bench_fp16.json" 2> "$OUT/bench_fp16.err"
-python3 bench.py --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+python3 bench.py --dtype fp8 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp8.json" 2> "$OUT/bench_fp8.err"
+python3 bench.py --dtype mixed --no-cpu-baseline --parity-images 2 > "$OUT/bench_mixed.json" 2> "$OUT/bench_mixed.err"
+python3 bench.py --dtype fp16 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp16.json" 2> "$OUT/bench_fp16.err"
+python3 bench.py --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"
+else
+python3 bench.py $W --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+fi
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py $W --no-cpu-baseline --parity-images 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     D="$OUT/pmc_$(echo $C | cut -d' ' -f1)"
     ITERS=2 timeout 600 rocprofv3 --pmc $C --output-format csv -d "$D" -o p -- python3 tools/prof_forward.py > "$D.log" 2>&1
 done
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $W --no-cpu-baseline --parity-images 0 --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
 python3 tools/step_timeline.py "$OUT/trace" > "$OUT/step_timeline.txt" 2>&1
 python3 tools/summarize_profile.py "$OUT" "$R" "$OUT/summary"
 cp "$OUT/step_timeline.txt" "$OUT/summary/${R}_step_timeline.txt"

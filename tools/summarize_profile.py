@@ -5,6 +5,8 @@ doubled on gfx950 for 16-B-per-lane streams, SQ_VALU_MFMA_BUSY_CYCLES counts sha
 import sys, os, csv, json, glob, shutil, collections
 
 src, R = sys.argv[1], sys.argv[2]
+SIZE, BATCH = int(os.environ.get("SIZE", "416")), int(os.environ.get("B", "32"))
+WORKLOAD = "YOLOv3 %dx%d batch %d bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)" % (SIZE, SIZE, BATCH)
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -32,7 +34,7 @@ def build_hash():
     passes were taken on exactly the code and plan it is running (a stale constant can never be printed)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from yolo_tensorflow_amd import buildinfo
-    return buildinfo.source_hash(416, 32, "bf16")
+    return buildinfo.source_hash(SIZE, BATCH, "bf16")
 
 
 def counters(sub):
@@ -81,7 +83,7 @@ if fetch and write:
     f_det = per_kernel(fetch, "FETCH_SIZE"); w_det = per_kernel(write, "WRITE_SIZE")
     f_tot = sum(v["sum"] for v in f_det.values()); w_tot = sum(v["sum"] for v in w_det.values())
     json.dump({
-        "workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
+        "workload": WORKLOAD,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; forwards segmented at their first dispatch (k_preprocess / the fused stem); KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md",
         "source_hash": build_hash(),
         "conv_launches": sum(v["launches"] for v in f_det.values()),
@@ -106,7 +108,7 @@ if mf:
         e["mfma_util_wall_2p4ghz"] = (busy / 1024.0) / (ns * 2.4) if busy and ns else None
         e["eff_clock_ghz"] = (gui / 8.0) / ns if gui and ns else None
     tb = sum(r.get("SQ_VALU_MFMA_BUSY_CYCLES") or 0 for r in rows.values()); tg = sum(r.get("GRBM_GUI_ACTIVE") or 0 for r in rows.values())
-    json.dump({"workload": "YOLOv3 416x416 batch 32 bf16, conv kernels of one forward (the last one of tools/prof_forward.py, tuned plan)",
+    json.dump({"workload": WORKLOAD,
                "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; forwards segmented at their first dispatch (k_preprocess / the fused stem); util = busy/(256 CUs*4 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs)",
                "source_hash": build_hash(),
                "conv_launches": sum(r["launches"] for r in rows.values()),

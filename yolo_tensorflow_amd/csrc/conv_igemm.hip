@@ -194,11 +194,34 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
     X(36, 1, 8, 11, 2, 2, 64, 0) X(37, 1, 8, 11, 2, 2, 64, 4) X(38, 1, 4, 11, 2, 2, 64, 4) X(39, 1, 4, 11, 2, 2, 64, 0)   \
     X(40, 1, 8, 11, 2, 2, 64, 0) X(41, 1, 8, 11, 1, 2, 64, 0) X(42, 1, 4, 11, 2, 2, 64, 0)        /* 40-: free-running waves */ \
     X(43, 1, 8, 11, 1, 3, 64, 0)
+// round 4 (ids follow the halo block: a configuration's id is its index in kCfgs): whole-Cout tiles for the stand-alone 1x1 layers
+// (every activation row enters ONE CU) and small-batch shapes.  (No tile wider than 256 channels: filters and bias are padded to
+// multiples of 256 rows, cout_pad.)
+#define CONV_CFGS_B(X)                                                                                 \
+    X(44, 1, 8, 6, 2, 2, 64, 0) X(45, 1, 8, 6, 2, 3, 64, 0) X(46, 2, 4, 3, 4, 2, 64, 0) X(47, 2, 4, 2, 4, 2, 64, 0)    \
+    X(48, 2, 4, 3, 2, 2, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0) X(50, 1, 8, 4, 2, 3, 64, 0) X(51, 2, 4, 2, 2, 3, 64, 0)
+
+// split fp16 storage (YOLO_FP16X2): the tile shapes instantiated with the two-pass epilogue
+#define CONV_CFGS_SPLIT(X)                                                                             \
+    X(0, 2, 2, 4, 4, 2, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(3, 2, 2, 2, 4, 3, 64, 0)  X(4, 4, 1, 4, 2, 2, 64, 0)    \
+    X(6, 2, 2, 4, 2, 2, 64, 0)  X(7, 2, 2, 4, 2, 3, 64, 0)  X(8, 4, 1, 4, 4, 2, 64, 0)  X(14, 2, 2, 2, 2, 2, 64, 0)   \
+    X(15, 2, 2, 2, 2, 4, 64, 0) X(16, 1, 4, 11, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0) X(33, 1, 4, 11, 2, 3, 64, 0) \
+    X(34, 1, 4, 6, 2, 3, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0)
+#define CONV_CFGS_SPLIT_HALO(X) X(40, 1, 8, 11, 2, 2, 64, 0) X(41, 1, 8, 11, 1, 2, 64, 0) X(43, 1, 8, 11, 1, 3, 64, 0)
+bool conv_cfg_split_ok(int cfg)
+{
+    switch (cfg) {
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return true;
+        CONV_CFGS_SPLIT(X) CONV_CFGS_SPLIT_HALO(X)
+#undef X
+    default: return false;
+    }
+}
 
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl, halo; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 0},
 #define XH(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 1},
-static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH)};
+static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X)};
 #undef X
 #undef XH
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
@@ -230,7 +253,7 @@ int conv_pick_cfg(const ConvArgs &a)
     return 0;
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI, int EB, bool H16 = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, bool UNI, int EB, bool H16 = false, bool SPLIT = false>
 static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BP = WP * TP * 16, BC = WC * TC * 16;
@@ -239,21 +262,21 @@ static hipError_t launch_u(const ConvArgs &a, hipStream_t s)
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL>();
     dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(64 * (WP * WC + NL));   // multiple of 8: see the XCD mapping
     if (lds > 65536) {
-        hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16>, lds);
+        hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16, SPLIT>, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16>), grid, block, lds, s, conv_tile_magic(a, BC, 0));
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, UNI, NL, false, EB, false, false, H16, SPLIT>), grid, block, lds, s, conv_tile_magic(a, BC, 0));
     return hipGetLastError();
 }
 
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, int EB, bool H16 = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL, int EB, bool H16 = false, bool SPLIT = false>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets: the activation window must stay below 2 GiB
     if (((double)a.N * a.H * a.W * a.in_stride + 2.0 * (a.W + 1) * a.in_stride) * EB >= 2147483648.0) return hipErrorInvalidValue;
     constexpr int BKE = BK * 2 / EB;
     if (a.Kpad % BKE) return hipErrorInvalidValue;
-    return (a.Cin_pad % BKE) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true, EB, H16>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false, EB, H16>(a, s);
+    return (a.Cin_pad % BKE) == 0 ? launch_u<WP, WC, TP, TC, NS, BK, NL, true, EB, H16, SPLIT>(a, s) : launch_u<WP, WC, TP, TC, NS, BK, NL, false, EB, H16, SPLIT>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
@@ -261,17 +284,31 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     // (16-bit storage: bf16, or fp16 -- the same tile table, the same kernels with the other MFMA and conversions)
     if (a.in_dt != DT_BF16 && a.in_dt != DT_F16) return hipErrorInvalidValue;
     if (a.in_dt == DT_F16 && a.out_dt != DT_F16 && a.out_dt != DT_F32) return hipErrorInvalidValue;
+    if (a.split) {
+        // split fp16 storage (YOLO_FP16X2): fp16 operands, 16-bit outputs written as hi | lo | hi blocks (fp32 head outputs as ever); a
+        // subset of the tile table is instantiated
+        if (a.in_dt != DT_F16 || (a.out_dt != DT_F16 && a.out_dt != DT_F32) || a.res || a.w2) return hipErrorInvalidValue;
+        switch (cfg) {
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2, true, true>(a, s);
+            CONV_CFGS_SPLIT(X)
+#undef X
+#define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_conv_halo13(a, id, s);
+            CONV_CFGS_SPLIT_HALO(X)
+#undef X
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a) ? launch_conv_c8_direct(a, s) : hipErrorInvalidValue;
     if (a.in_dt == DT_F16)
         switch (cfg) {
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2, true>(a, s);
-            CONV_CFGS(X)
+            CONV_CFGS(X) CONV_CFGS_B(X)
 #undef X
         default: break;
         }
     switch (cfg) {
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2>(a, s);
-        CONV_CFGS(X)
+        CONV_CFGS(X) CONV_CFGS_B(X)
 #undef X
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_conv_halo13(a, id, s);
         CONV_CFGS_HALO(X)

@@ -164,7 +164,10 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // 27 % fewer LDS bytes per FLOP -- was bit-identical and ran the 26x26 K-step in 0.99 us, the same as the 176 x 32 forms: every
 // variant lands on ~1.45 PFLOP/s, the rate the chip sustains on random bf16 operands once its clock management has reacted (the
 // CDNA4 guide's 'DVFS give-back': a cycle saved in an MFMA-dense main loop comes back partly as a lower clock).)
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false>
+// SPLIT (H16 only; YOLO_FP16X2): 16-bit outputs are stored as split fp16 pairs -- hi = f16(v) into channel blocks 0 and 2, lo = f16(v - hi)
+// into block 1 (blocks a.out_blk elements apart) -- by a second pass of the epilogue's LDS tile; the K loop is the ordinary fp16 one, run over
+// the 3 x Cin 'channels' hi | lo | hi of the input against filter rows W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -175,8 +178,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     constexpr int BP = WP * TP * 16;           // output pixels per workgroup
     constexpr int BC = WC * TC * 16;           // output channels per workgroup
     static_assert(BK == 64 || BK == 32, "K-step");
+    static_assert(BC <= 256, "filters and bias are padded to multiples of 256 output channels (cout_pad): a wider tile would read past them");
     static_assert(EB == 2 || (EB == 1 && BK == 64), "fp8 operands need the 128-B-row form");
     static_assert(!H16 || EB == 2, "fp16 is a 16-bit storage type");
+    static_assert(!SPLIT || (H16 && !DIAG), "split pairs are fp16 pairs");
     constexpr int RB = BK * 2;                 // bytes of one LDS tile row (one K-step of one pixel / filter)
     constexpr int EPC = 16 / EB;               // elements per 16-B chunk
     constexpr int BKE = RB / EB;               // K elements per step
@@ -231,7 +236,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // activation rows (all channel tiles of a pixel tile) and walk the filter slices together.
     const int M = a.N * a.Ho * a.Wo;
     const int tilesC = (a.Cout + BC - 1) / BC;
-    const int tilesP = HALO ? a.N * (a.H / HB) * (a.W / HB) : (M + BP - 1) / BP;
+    // (halo form: a size that is not a multiple of 13 gets ragged blocks on its bottom / right edge -- their columns past the image read
+    //  zeros from the halo tile, as padding does, and are never stored)
+    const int hbr = HALO ? (a.H + HB - 1) / HB : 0, hbc = HALO ? (a.W + HB - 1) / HB : 0;      // block rows / columns per image
+    const int tilesP = HALO ? a.N * hbr * hbc : (M + BP - 1) / BP;
     const int per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= tilesP * tilesC) return;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int ct = tile - pt * tilesC;
     int bn = 0, by = 0, bx = 0;                // halo form: image, block row, block column of this workgroup's 13x13 block
     if constexpr (HALO) {
-        const int bpr = a.W / HB, bpi = bpr * (a.H / HB);
+        const int bpr = hbc, bpi = hbc * hbr;
         bn = fast_div(pt, a.bpi_mul, a.bpi_shift); const int r = pt - bn * bpi; by = fast_div(r, a.bpr_mul, a.bpr_shift); bx = r - by * bpr;
     }
 
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // (8-wave shapes only: in the 4-wave 176x128 shapes the extra live registers push the kernel past 256 VGPRs and cost the
     // second resident workgroup per CU -- measured slower overall even where the pair itself got faster)
     // (bf16: not in the role-split shapes -- the tail's addresses, hoisted above the K loop, push their 168-VGPR budget into spills)
-    constexpr bool TAIL_OK = WP == 1 && NC == 8 && (EB == 2 ? NL == 0 && (BC == 256 || BC == 128) : BC == 256);
+    constexpr bool TAIL_OK = !SPLIT && WP == 1 && NC == 8 && (EB == 2 ? NL == 0 && (BC == 256 || BC == 128) : BC == 256);
     // (Tried and dropped: placing one LDS-DMA of the next stage behind every MFMA group with sched_group_barrier instead of
     // issuing the whole stage first.  A/B on one MI355X box, YOLOv3-416 batch 32: 2 % SLOWER in both bf16 (3.48 vs 3.40 ms)
     // and fp8 (2.39 vs 2.34 ms) -- a DMA blocks its wave's issue for ~60 cycles wherever it is placed, and the MFMA pipe
@@ -462,11 +470,16 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     unsigned long long t_wait = 0, t_issue = 0, t_mma = 0, t_all0 = 0, t_first = 0, te1 = 0, te2 = 0, te3 = 0, te4 = 0, te5 = 0, te6 = 0;
     auto stamp = [&]() -> unsigned long long {
         unsigned long long t = 0;
+        if (DIAG && !a.dbg_light) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+        return t;
+    };
+    auto stamp_loop = [&]() -> unsigned long long {      // the two stamps around the K loop: always taken in a diagnostic build
+        unsigned long long t = 0;
         if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); }
         return t;
     };
     unsigned long long rt0 = 0;
-    if (DIAG) { t_all0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (DIAG) { t_all0 = stamp_loop(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // one K-step.  `fill` / `sb`: the stage being filled and the stage being multiplied.  They are distinct __restrict__ parameters
     // on purpose: hipcc orders every ds_read behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0) before the first
     // fragment read of each K-step, i.e. the loads just issued for the NEXT step were waited for before this step's
@@ -564,7 +577,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         mma_phase([&](int j) { return sb + offx + j * 16 * RB; }, [&](int i) { return sb + offw + i * 16 * RB; }, sw0, sw1);
         __builtin_amdgcn_s_setprio(0);
         if (DIAG) {
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            if (!a.dbg_light) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
             const unsigned long long s3 = stamp();
             t_wait += s1 - s0; t_issue += s2 - s1; t_mma += s3 - s2;
         }
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         __builtin_amdgcn_s_setprio(2);
         mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HP + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
         __builtin_amdgcn_s_setprio(0);
-        if (DIAG) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); t_mma += stamp() - s2; }
+        if (DIAG) { if (!a.dbg_light) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); t_mma += stamp() - s2; }
     };
     if constexpr (HALO) {
         char *const act0 = smem, *const act1 = smem + ACT_BYTES, *const flt0 = smem + 2 * ACT_BYTES, *const flt1 = flt0 + FSTAGE;
@@ -678,8 +691,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             }
         }
     }
-    unsigned long long t_loop_end = 0;
-    if (DIAG) t_loop_end = stamp();
+    unsigned long long t_loop_end = 0, rt_loop = 0;
+    if (DIAG) { t_loop_end = stamp_loop(); rt_loop = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- epilogue ----
     // bf16 / fp8 stores and shortcut loads go through buffer descriptors based at this workgroup's first pixel and channel: the lane
@@ -697,13 +710,15 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     };
     // byte offset (from the tile origin, channel tile ct) of 16-byte piece c of the tile -- row-major, `cpr` pieces of `cpp` channels
     // per row, pixel stride `sb` bytes -- or OOB_OFFSET when the piece is not stored; also returns the piece's row and position
+    // halo form: rows / columns of this block inside the image (13 unless the block is a ragged one on the bottom / right edge)
+    const unsigned ylim = HALO ? (unsigned)(a.H - by * HB < HB ? a.H - by * HB : HB) : 0u, xlim = HALO ? (unsigned)(a.W - bx * HB < HB ? a.W - bx * HB : HB) : 0u;
     auto piece_off = [&](int c, int cpr, int cpp, unsigned sb, int &row, int &cc) -> unsigned {
         row = c / cpr; cc = c - row * cpr;
         unsigned rel; bool ok;
         if constexpr (HALO) {
             static_assert(HB == 13 && BP < 350, "row / 13 as (row * 79) >> 10");
             const unsigned y = __umul24((unsigned)row, 79u) >> 10, x = (unsigned)row - __umul24(y, 13u);
-            rel = __umul24(y, (unsigned)a.W) + x; ok = row < HB * HB;
+            rel = __umul24(y, (unsigned)a.W) + x; ok = y < ylim && x < xlim;       // (y < 13 is row < 169)
         }
         else { rel = (unsigned)row; ok = row < rows_left; }
         ok = ok && ct * BC + cc * cpp < a.Cout;
@@ -764,28 +779,37 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         // writes remain behind it.  The stamped build moved 1 300 cycles in front of the barrier and took 100 off the phase behind it: that
         // phase is the LDS store path -- 176 ds_write_b64 per wave pair at ~12 cycles each -- not the arithmetic; the step got 1.7 % slower.)
         const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
-        if (is_consumer)
+        // accumulators -> 16-bit tile in LDS.  LOW (SPLIT only): the low halves of the split pairs, lo = f16(v - f32(f16(v)))
+        auto fill_tile = [&](auto lowc) {
+            constexpr bool LOW = decltype(lowc)::value;
+            if (is_consumer)
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
-            const f32x4 bv = bvs[i], sv = svs[i];
+            for (int i = 0; i < TC; ++i) {
+                const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
+                const f32x4 bv = bvs[i], sv = svs[i];
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                f32x4 v = acc[i][j];
-                if (EB == 1) v = v * sv;
-                v = v + bv;
-                const f32x4 t = v * slope;                    // leaky: max(v, 0.1 v) == v > 0 ? v : 0.1 v; linear: max(v, v)
+                for (int j = 0; j < TP; ++j) {
+                    f32x4 v = acc[i][j];
+                    if (EB == 1) v = v * sv;
+                    v = v + bv;
+                    const f32x4 t = v * slope;                    // leaky: max(v, 0.1 v) == v > 0 ? v : 0.1 v; linear: max(v, v)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], t[q]);
-                uint2 pk;
-                pk.x = pack16x2<H16>(v[0], v[1]);
-                pk.y = pack16x2<H16>(v[2], v[3]);
-                *(uint2 *)(smem + (HALO ? prow[j] : ((wpi * TP + j) * 16 + l15) * RS) + chl * 2) = pk;
-                if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (one straight-line block of TC * TP sub-tiles otherwise)
+                    for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], t[q]);
+                    uint2 pk;
+                    pk.x = pack16x2<H16>(v[0], v[1]);
+                    pk.y = pack16x2<H16>(v[2], v[3]);
+                    if constexpr (LOW) {
+                        pk.x = pack16x2<H16>(v[0] - unpack16_lo<H16>(pk.x), v[1] - unpack16_hi<H16>(pk.x));
+                        pk.y = pack16x2<H16>(v[2] - unpack16_lo<H16>(pk.y), v[3] - unpack16_hi<H16>(pk.y));
+                    }
+                    *(uint2 *)(smem + (HALO ? prow[j] : ((wpi * TP + j) * 16 + l15) * RS) + chl * 2) = pk;
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (one straight-line block of TC * TP sub-tiles otherwise)
+                }
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        block_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            block_barrier();
+        };
+        fill_tile(std::false_type{});
         if (DIAG) te2 = stamp();
         // fused 1x1 tail (bf16): eight consumer waves = T2G groups of T2W 16-channel tiles x T2P parts of the tile's pixel sub-tiles
         // (T2W = 2 in the halo forms, 1 in the tiled 8-wave shape, which has no registers for 64 of filter fragments).  A wave's filter
@@ -897,7 +921,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // pieces to COMPLETE -- five memory operations in flight per wave instead of all of them.  (The tail's write-back stays a
             // run-time branch: an LDS store does not touch vmcnt, and a third copy of the loop costs registers.)
             const bool tail_wb = TAIL_OK && EB == 2 && a.w2;
-            auto store_tile = [&](auto resc) {
+            // o1: byte offset added to every piece's address; o2 (SPLIT): a second address every piece is ALSO stored at, or ~0u
+            auto store_tile = [&](auto resc, const unsigned o1, const unsigned o2) {
                 constexpr bool RES = decltype(resc)::value;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -917,10 +942,19 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         }
                         if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off + o1, 0, 0);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
+                    if constexpr (SPLIT) if (o2 != ~0u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off + o2, 0, 0);
                 }
             };
-            if (res) store_tile(std::true_type{}); else store_tile(std::false_type{});
+            if constexpr (SPLIT) {
+                // the tile in LDS holds the high halves: blocks 0 and 2 of every pixel; then the low halves go through the same tile into block 1
+                const unsigned blk = (unsigned)a.out_blk * 2u;
+                store_tile(std::false_type{}, 0u, 2u * blk);
+                block_barrier();                                  // everybody has read its pieces of the hi tile
+                fill_tile(std::true_type{});
+                store_tile(std::false_type{}, blk, ~0u);
+            }
+            else if (res) store_tile(std::true_type{}, 0u, ~0u); else store_tile(std::false_type{}, 0u, ~0u);
             if (DIAG) te3 = stamp();
             if constexpr (TAIL_OK && EB == 2) if (a.w2) {
                 // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.  Wave (t2g, t2p)
@@ -1039,12 +1073,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     }
     if (DIAG && a.dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = stamp();
+        const unsigned long long t_end = stamp_loop();
         unsigned long long *d = a.dbg + ((size_t)tile * NTOT + wave_id) * 16;
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         d[0] = t_wait; d[1] = t_issue; d[2] = t_mma; d[3] = t_loop_end - t_all0; d[4] = t_end - t_loop_end;
         d[6] = t_all0 - t_top; d[7] = t_first - t_all0; d[8] = te1 - t_loop_end; d[9] = te2 - te1; d[10] = te3 - te2; d[11] = t_end - (te6 ? te6 : te3);
-        d[12] = te4 ? te4 - te3 : 0; d[13] = te4 ? te5 - te4 : 0; d[14] = te4 ? te6 - te5 : 0; d[15] = 0;
+        d[12] = te4 ? te4 - te3 : 0; d[13] = te4 ? te5 - te4 : 0; d[14] = te4 ? te6 - te5 : 0;
+        d[15] = (t_loop_end - t_all0) * 100ull / (rt_loop - rt0 ? rt_loop - rt0 : 1);      // shader MHz over the K loop alone (s_memtime / s_memrealtime, 100 MHz)
         d[5] = ((unsigned long long)KT << 40) | ((t_end - t_all0) * 100ull / (rt1 - rt0 ? rt1 - rt0 : 1));   // KT | shader MHz (realtime = 100 MHz)
     }
 #endif

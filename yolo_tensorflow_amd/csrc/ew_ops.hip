@@ -371,6 +371,80 @@ hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, flo
     return hipGetLastError();
 }
 
+// ---- split fp16 storage (YOLO_FP16X2): a value v is the pair hi = f16(v), lo = f16(v - hi) -- 22 significant bits out of two 11-bit
+//      halves.  A tensor is [pixel][3 * Cp] f16 (Cp = channels rounded up to 8): blocks hi | lo | hi, so that an ordinary fp16 conv over
+//      3 * Cp "channels" with filter rows W_hi | W_hi | W_lo computes W_hi x_hi + W_hi x_lo + W_lo x_hi (what is dropped is W_lo x_lo,
+//      2^-22 of the product): the conv kernels need nothing but a second store pass (conv_igemm_kernel.h, SPLIT).  These are the
+//      memory-bound pieces around them. ----
+__device__ __forceinline__ void split8(const float *v, uint4 &H, uint4 &L)
+{
+    typedef Elt<f16_t> E;
+    H = uint4{E::pk(v[0], v[1]), E::pk(v[2], v[3]), E::pk(v[4], v[5]), E::pk(v[6], v[7])};
+    const uint32_t w[4] = {H.x, H.y, H.z, H.w};
+    float lo[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const E::h2 h = __builtin_bit_cast(E::h2, w[i]); lo[2 * i] = v[2 * i] - (float)h[0]; lo[2 * i + 1] = v[2 * i + 1] - (float)h[1]; }
+    L = uint4{E::pk(lo[0], lo[1]), E::pk(lo[2], lo[3]), E::pk(lo[4], lo[5]), E::pk(lo[6], lo[7])};
+}
+__device__ __forceinline__ void join8(const f16_t *p, int Cp, float *v)
+{
+    float h[8], l[8];
+    Elt<f16_t>::load8(p, h); Elt<f16_t>::load8(p + Cp, l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = h[i] + l[i];
+}
+__device__ __forceinline__ void put_split8(f16_t *p, int Cp, const float *v)
+{
+    uint4 H, L; split8(v, H, L);
+    *(uint4 *)p = H; *(uint4 *)(p + Cp) = L; *(uint4 *)(p + 2 * Cp) = H;
+}
+__global__ void k_split_from_f32(const float *in, int is, f16_t *out, int Cp, size_t npix)
+{
+    const int c8 = Cp / 8;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8) return;
+    size_t p = idx / c8; int g = (int)(idx - p * c8);
+    float v[8]; Elt<float>::load8(in + p * is + g * 8, v);
+    put_split8(out + p * 3 * Cp + g * 8, Cp, v);
+}
+__global__ void k_split_to_f32(const f16_t *in, int Cp, float *out, int os, size_t npix)
+{
+    const int c8 = Cp / 8;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8) return;
+    size_t p = idx / c8; int g = (int)(idx - p * c8);
+    float v[8]; join8(in + p * 3 * Cp + g * 8, Cp, v);
+    Elt<float>::store8(out + p * os + g * 8, v);
+}
+// shortcut on split tensors: (a_hi + a_lo) + (b_hi + b_lo), split again (each parenthesis is exact in fp32 when the pair came from split8)
+__global__ void k_add_split(const f16_t *a, const f16_t *b, f16_t *o, int Cp, size_t npix)
+{
+    const int c8 = Cp / 8;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * c8) return;
+    size_t p = idx / c8; int g = (int)(idx - p * c8);
+    float x[8], y[8];
+    join8(a + p * 3 * Cp + g * 8, Cp, x); join8(b + p * 3 * Cp + g * 8, Cp, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = x[i] + y[i];
+    put_split8(o + p * 3 * Cp + g * 8, Cp, x);
+}
+hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int Cp, size_t npix, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_split_from_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, in, in_stride, (f16_t *)out, Cp, npix);
+    return hipGetLastError();
+}
+hipError_t launch_split_to_f32(const void *in, int Cp, float *out, int out_stride, size_t npix, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_split_to_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)in, Cp, out, out_stride, npix);
+    return hipGetLastError();
+}
+hipError_t launch_add_split(const void *a, const void *b, void *out, int Cp, size_t npix, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_add_split, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)a, (const f16_t *)b, (f16_t *)out, Cp, npix);
+    return hipGetLastError();
+}
+
 // ---- darknet letterbox_image (DN/image.c:960-981) fused with the layout change: a planar float image of any size ->
 //      aspect-preserving resize_image (DN/image.c:1347-1393: horizontal pass then vertical pass, scales (in-1)/(out-1),
 //      last column / row copied) embedded at the centre of a 0.5-filled S x S canvas, written as the 8-channel

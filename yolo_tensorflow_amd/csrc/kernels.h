@@ -32,6 +32,8 @@ struct ConvArgs {
     // per-output-channel dequantisation factor of the accumulator (filter scale; input scales are folded into the
     // filters), `out_inv_scale` = 1 / scale of the output tensor, `res_scale` = scale of the residual tensor.
     int in_dt;
+    int split;                           // 1: split fp16 output (YOLO_FP16X2): every 16-bit output value is stored as hi | lo | hi in three blocks `out_blk` elements apart
+    int out_blk;
     const float *oscale;                 // [Cout_pad] or nullptr (== 1)
     float out_inv_scale, res_scale;
     float mid_scale, mid_inv_scale;      // fused shortcut: this conv's own output scale (quantised before the add)
@@ -54,6 +56,7 @@ struct ConvArgs {
     // obj_out[pixel * obj_na + an]; nullptr: off.  obj_mul / obj_shift: division by obj_attrs (conv_magic)
     float *obj_out; int obj_attrs, obj_na; uint32_t obj_mul, obj_shift;
     unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
+    int dbg_light;                       // diagnostic builds only: 1 = stamp once around the K loop and nothing inside it (the in-kernel clock measurement)
     // division constants of the tile decode, filled by the launcher for its tile shape (conv_tile_magic): channel tiles per pixel
     // tile; halo form: 13x13 blocks per image and per block row
     uint32_t tc_mul, tc_shift, bpi_mul, bpi_shift, bpr_mul, bpr_shift;
@@ -80,7 +83,7 @@ inline ConvArgs conv_tile_magic(const ConvArgs &a0, int BC, int hb)
 {
     ConvArgs a = a0;
     conv_magic((uint32_t)((a.Cout + BC - 1) / BC), a.tc_mul, a.tc_shift);
-    if (hb > 0) { conv_magic((uint32_t)((a.H / hb) * (a.W / hb)), a.bpi_mul, a.bpi_shift); conv_magic((uint32_t)(a.W / hb), a.bpr_mul, a.bpr_shift); }
+    if (hb > 0) { const int br = (a.H + hb - 1) / hb, bc = (a.W + hb - 1) / hb; conv_magic((uint32_t)(br * bc), a.bpi_mul, a.bpi_shift); conv_magic((uint32_t)bc, a.bpr_mul, a.bpr_shift); }      // (ragged edge blocks included)
     return a;
 }
 
@@ -102,6 +105,7 @@ hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant
 bool conv_cfg_tail_ok(int cfg, int cout, bool fp8);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
+bool conv_cfg_split_ok(int cfg);      // tile configurations instantiated for split fp16 storage (YOLO_FP16X2)
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
 // fused stem: conv 3x3/s1 (3 -> 32) + conv 3x3/s2 (32 -> 64), bf16 (conv_stem.hip)
@@ -160,6 +164,10 @@ hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s);
 hipError_t launch_local(const TView &in, const TView &out, const void *w, const float *bias, int k, int stride, int pad, int act, hipStream_t s);
 hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s, float scale = 1.f);   // dense NHWC fp32 copy (* scale)
 hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, float scale = 1.f);   // (in * scale) -> view
+// split fp16 storage (YOLO_FP16X2; ew_ops.hip): tensors [pixel][3 * Cp] f16 = hi | lo | hi blocks of Cp = roundup(C, 8) channels
+hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int Cp, size_t npix, hipStream_t s);   // dense-ish fp32 [pixel][in_stride >= Cp] -> split
+hipError_t launch_split_to_f32(const void *in, int Cp, float *out, int out_stride, size_t npix, hipStream_t s);      // split -> fp32 (hi + lo)
+hipError_t launch_add_split(const void *a, const void *b, void *out, int Cp, size_t npix, hipStream_t s);            // shortcut on split tensors
 
 // ---- head decode + postprocess (post_ops.hip) ---------------------------------------------------
 struct DecodeArgs {

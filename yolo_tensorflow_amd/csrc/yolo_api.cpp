@@ -10,7 +10,7 @@ yolo_ctx *yolo_create(const yolo_config *cfg, char *err, size_t err_len)
     auto bail = [&](yolo_ctx *c, const std::string &m) -> yolo_ctx * { if (err && err_len) snprintf(err, err_len, "%s", m.c_str()); if (c) yolo_destroy(c); return nullptr; };
     if (!cfg || cfg->struct_size != sizeof(yolo_config)) return bail(nullptr, "yolo_create: bad yolo_config (struct_size)");
     if (cfg->max_batch < 1) return bail(nullptr, "yolo_create: max_batch < 1");
-    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32 && cfg->dtype != YOLO_FP8 && cfg->dtype != YOLO_FP16) return bail(nullptr, "yolo_create: dtype");
+    if (cfg->dtype != YOLO_BF16 && cfg->dtype != YOLO_FP32 && cfg->dtype != YOLO_FP8 && cfg->dtype != YOLO_FP16 && cfg->dtype != YOLO_FP16X2) return bail(nullptr, "yolo_create: dtype");
     yolo_ctx *c = new yolo_ctx();
     c->device = cfg->device; c->max_batch = cfg->max_batch; c->dtype = cfg->dtype; c->semantics = cfg->semantics;
     c->decode = cfg->decode; c->keep_layers = cfg->keep_layers;
@@ -36,7 +36,7 @@ void yolo_destroy(yolo_ctx *c)
     for (void *p : c->phys) if (p) hipFree(p);
     for (auto &L : c->layers) { if (L.d_w) hipFree(L.d_w); if (L.d_b) hipFree(L.d_b); if (L.d_sc) hipFree(L.d_sc); if (L.d_wf) hipFree(L.d_wf); if (L.d_obj) hipFree(L.d_obj); }
     void *ptrs[] = {c->input.ptr, c->d_zeros, c->d_stage, c->d_det, c->d_scores, c->d_labels, c->d_cand, c->d_keys, c->d_sbox, c->d_slabel, c->d_sscore, c->d_boxes, c->d_counts,
-                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr, c->d_srow, c->d_rows, c->d_lean_list, c->d_lean_cnt};
+                    c->d_dn_rec, c->d_dn_src, c->d_dn_count, c->d_dn_last, c->d_box4, c->s2d.ptr, c->d_srow, c->d_rows, c->d_lean_list, c->d_lean_cnt, c->d_f32a, c->d_f32b};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -203,10 +203,18 @@ int yolo_layer_output(yolo_ctx *c, int index, int n, float *out, size_t out_floa
         vs = c->eff_scale[index];
         if (vs != vs) { hipFree(tmp); return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d concatenates tensors with different fp8 scales; read its sources", index); }
     }
-    hipError_t e = launch_to_f32(v, tmp, c->stream, vs);
+    hipError_t e = hipSuccess;
+    float *wide = nullptr;
+    if (c->split() && v.dt == DT_F16) {        // split pairs: join into a Cp-strided fp32 image first, then gather the C logical channels
+        const int cp = v.stride / 3;
+        e = hipMalloc((void **)&wide, (size_t)n * L.H * L.W * cp * 4);
+        if (e == hipSuccess) e = launch_split_to_f32(v.ptr, cp, wide, cp, (size_t)n * L.H * L.W, c->stream);
+        v.ptr = wide; v.stride = cp; v.dt = DT_F32;
+    }
+    if (e == hipSuccess) e = launch_to_f32(v, tmp, c->stream, vs);
     if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, need * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(tmp);
+    hipFree(tmp); if (wide) hipFree(wide);
     if (e != hipSuccess) return fail(c, YOLO_ERR_HIP, "layer_output: %s", hipGetErrorString(e));
     return YOLO_OK;
 }

@@ -109,7 +109,10 @@ struct yolo_ctx {
     // layer i (1 by default); eff_scale[i] is the scale of the tensor layer i's view holds (inherited through
     // upsample / maxpool / reorg / single-input route; NaN for multi-input routes, which are per channel).
     std::vector<float> user_scale, eff_scale;
-    int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : dtype == YOLO_FP16 ? DT_F16 : DT_BF16; }
+    // split fp16 storage (YOLO_FP16X2): a logical tensor of C channels is [pixel][3 * Cp] f16, Cp = roundup(C, 8): hi | lo | hi blocks
+    bool split() const { return dtype == YOLO_FP16X2; }
+    float *d_f32a = nullptr, *d_f32b = nullptr; size_t f32_cap = 0;      // split mode: fp32 staging of one tensor (input conversion, upsample / pool / reorg run in fp32 between a join and a split)
+    int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : (dtype == YOLO_FP16 || dtype == YOLO_FP16X2) ? DT_F16 : DT_BF16; }
     bool half_like() const { return dtype == YOLO_BF16 || dtype == YOLO_FP16; }      // 16-bit storage: the same kernels, the same plan
     int gran() const { return dtype == YOLO_FP8 ? 16 : 8; }            // channel granule = one 16-B piece (8 for fp32 too)
     size_t esize() const { return dt_size(act_dt()); }
@@ -131,7 +134,8 @@ uint16_t f2bf(float f);
 uint16_t f2h(float f);
 uint8_t f2e4m3(float f);
 void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
-               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics = YOLO_SEM_TF);
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics = YOLO_SEM_TF, bool split = false);
+float h2f(uint16_t h);
 void resolve_scales(yolo_ctx *c);
 void channel_scales(const yolo_ctx *c, int idx, std::vector<float> &out);
 int tail_fragments(yolo_ctx *c);

@@ -23,12 +23,55 @@ TView make_view(void *p, int n, int h, int w, int c, int stride, int dt) { TView
 extern "C" {
 
 // ---- single operators -----------------------------------------------------------------------
+// yolo_op_conv2d for dtype YOLO_FP16X2: x (and the residual) enter as split fp16 pairs, the filters as W_hi | W_hi | W_lo rows, the conv runs
+// on the SPLIT instantiation, the shortcut (if any) as the separate k_add_split launch of that configuration, the result is joined to fp32
+static int op_conv2d_split(const float *x, int n, int h, int w, int cin, const float *w_hwio, const float *bias, int k, int stride,
+                           int cout, int act, const float *residual, float *out, int tile_cfg, int device)
+{
+    if (cin % 8 || cout % 8) { g_op_err = "conv2d (fp16x2): channel counts must be multiples of 8"; return YOLO_ERR_INVALID; }
+    OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
+    Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act; L.in_dt = DT_F16;
+    L.cin = cin; L.cin_pad = 3 * cin; L.kpad = roundup(k * k * L.cin_pad, 64); L.cout_pad = roundup(cout, 256);
+    const int ho = (h + 2 * L.pad - k) / stride + 1, wo = (w + 2 * L.pad - k) / stride + 1;
+    std::vector<float> oihw((size_t)cout * cin * k * k), b0(cout, 0.f);
+    for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int ci = 0; ci < cin; ++ci) for (int o = 0; o < cout; ++o)
+        oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] = w_hwio[(((size_t)kh * k + kw) * cin + ci) * cout + o];
+    if (bias) memcpy(b0.data(), bias, (size_t)cout * 4);
+    std::vector<uint8_t> wbuf; std::vector<float> bv, osc; pack_conv(L, b0.data(), oihw.data(), DT_F16, nullptr, wbuf, bv, osc, YOLO_SEM_TF, true);
+    void *d_w = S.upload(wbuf.data(), wbuf.size()); float *d_b = (float *)S.upload(bv.data(), bv.size() * 4);
+    const size_t pin = (size_t)n * h * w, pout = (size_t)n * ho * wo;
+    float *d_x32 = (float *)S.upload(x, pin * cin * 4);
+    void *d_x = S.alloc(pin * 3 * cin * 2), *d_o = S.alloc(pout * 3 * cout * 2), *d_z = S.alloc(4096);
+    float *d_o32 = (float *)S.alloc(pout * cout * 4);
+    if (S.rc) { g_op_err = "conv2d: allocation failed"; return S.rc; }
+    if (!S.ok(launch_split_from_f32(d_x32, cin, d_x, cin, pin, S.s))) { g_op_err = S.err; return S.rc; }
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = d_x; a.in_stride = 3 * cin; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = 3 * cout; a.out_dt = DT_F16; a.in_dt = DT_F16;
+    a.split = 1; a.out_blk = cout; a.out_inv_scale = a.res_scale = a.mid_scale = a.mid_inv_scale = 1.f;
+    a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
+    a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, DT_F16); a.act = act; a.zeros = d_z;
+    conv_finalize(a);
+    int cfg = tile_cfg >= 0 ? tile_cfg : 6;
+    if (!conv_cfg_split_ok(cfg) || (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
+    if (!S.ok(launch_conv_bf16(a, cfg, S.s))) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
+    if (residual) {
+        float *d_r32 = (float *)S.upload(residual, pout * cout * 4); void *d_r = S.alloc(pout * 3 * cout * 2);
+        if (S.rc) return S.rc;
+        if (!S.ok(launch_split_from_f32(d_r32, cout, d_r, cout, pout, S.s)) || !S.ok(launch_add_split(d_o, d_r, d_o, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
+    }
+    if (!S.ok(launch_split_to_f32(d_o, cout, d_o32, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
+    S.download(out, d_o32, pout * cout * 4);
+    if (S.rc) g_op_err = "conv2d: " + std::string(hipGetErrorString(hipGetLastError()));
+    return S.rc;
+}
+
 int yolo_op_conv_num_cfgs(void) { return conv_num_cfgs(); }
 
 int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_hwio, const float *bias, int k, int stride,
                    int cout, int act, const float *residual, float *out, int dtype, int tile_cfg, int device)
 {
     if (!x || !w_hwio || !out || n < 1 || (k != 1 && k != 3) || stride < 1) { g_op_err = "conv2d: bad arguments"; return YOLO_ERR_INVALID; }
+    if (dtype == YOLO_FP16X2) return op_conv2d_split(x, n, h, w, cin, w_hwio, bias, k, stride, cout, act, residual, out, tile_cfg, device);
     OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
     // dtype YOLO_FP8: x, residual and the result are e4m3 tensors of scale 1 (the inputs are quantised here first)
     const bool f32 = dtype == YOLO_FP32; const int dt = f32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : dtype == YOLO_FP16 ? DT_F16 : DT_BF16; const size_t es = dt_size(dt);
@@ -72,14 +115,18 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         const bool dwide = !strcmp(getenv("YOLO_CONV_DIAG"), "free4");        // four waves of 176 x 64
         const bool dfree = (dwide || !strcmp(getenv("YOLO_CONV_DIAG"), "free")) && conv_halo13_ok(a) && dt == DT_BF16;
         const int wv = dfree && !dwide ? 8 : 4;
-        const long tiles = dfree ? (long)n * (h / 13) * (w / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
+        const long tiles = dfree ? (long)n * ((h + 12) / 13) * ((w + 12) / 13) * ((cout + 255) / 256) : (((long)n * ho * wo + 175) / 176) * ((cout + 127) / 128);
         a.dbg = (unsigned long long *)S.alloc((size_t)tiles * wv * 16 * 8);
+        a.dbg_light = getenv("YOLO_CONV_DIAG_LIGHT") ? 1 : 0;      // stamps around the K loop only (the clock measurement)
         if (dfree && !dwide && getenv("YOLO_CONV_DIAG_TAIL") && cout == 256) {
             // time the fused 1x1 tail too: any 128 x 256 filter block will do (the main filters' first rows), output to scratch
             a.w2 = a.wt; a.w2f = a.wt; a.K2pad = a.Kpad; a.b2 = a.bias; a.act2 = ACT_LEAKY; a.out2_stride = 128;
             a.out2 = S.alloc((size_t)n * ho * wo * 128 * 2);
         }
-        for (int rep = 0; rep < 200; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s, dwide ? 1 : 0) : launch_conv_diag(a, S.s);     // long enough for the clock to settle under load
+        // long enough for the clock to settle under load: the CDNA4 guide asks for >= 2 s of back-to-back launches before the stamps are read
+        // (YOLO_CONV_DIAG_REPS; the stamps of the LAST launch are what is downloaded)
+        const int reps = getenv("YOLO_CONV_DIAG_REPS") ? atoi(getenv("YOLO_CONV_DIAG_REPS")) : 200;
+        for (int rep = 0; rep < reps; ++rep) e = dfree ? launch_conv_halo13_diag(a, S.s, dwide ? 1 : 0) : launch_conv_diag(a, S.s);
         std::vector<unsigned long long> hd((size_t)tiles * wv * 16);
         S.download(hd.data(), a.dbg, hd.size() * 8);
         double sum[16] = {0}; size_t cnt = hd.size() / 16;
@@ -87,8 +134,10 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
         for (size_t i = 0; i < cnt; ++i)
             for (int q = 0; q < 16; ++q) sum[q] += q == 5 ? (double)(hd[i * 16 + 5] & 0xffffffffffull) : (double)hd[i * 16 + q];
         for (double &v : sum) v /= cnt;
-        fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz\n",
-                cnt, kt, sum[0] / kt, sum[1] / kt, sum[2] / kt, sum[3] / kt, sum[4], sum[5]);
+        std::vector<unsigned long long> kclk(cnt); for (size_t i = 0; i < cnt; ++i) kclk[i] = hd[i * 16 + 15];
+        std::nth_element(kclk.begin(), kclk.begin() + cnt / 2, kclk.end()); const double kmed = cnt ? (double)kclk[cnt / 2] : 0.0;
+        fprintf(stderr, "diag: waves %zu KT %llu | per K-step cycles: wait+barrier %.0f  issue %.0f  ds_read+mfma %.0f  (loop total/KT %.0f) | epilogue %.0f cycles | shader clock %.0f MHz (K loop alone %.0f MHz, median over waves %.0f)\n",
+                cnt, kt, sum[0] / kt, sum[1] / kt, sum[2] / kt, sum[3] / kt, sum[4], sum[5], sum[15], kmed);
         fprintf(stderr, "diag: setup (first instruction -> prologue issued) %.0f | first wait (prologue data + barrier) %.0f | epilogue: barrier %.0f  acc->LDS + barrier %.0f  shortcut add + store issue %.0f  store drain %.0f\n",
                 sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
         if (a.w2) fprintf(stderr, "diag: fused 1x1 tail: barrier %.0f  fragments + MFMA + pack %.0f  barrier %.0f (then the tail's stores, in `store drain`)\n", sum[12], sum[13], sum[14]);

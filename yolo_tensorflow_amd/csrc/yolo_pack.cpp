@@ -54,8 +54,16 @@ uint8_t f2e4m3(float f)
 // fold + pack one conv's parameters (host).  w_oihw: [cout][cin][k][k].  wdt: element type of the packed filters.
 // fp8: `in_scale` (per input channel, or null = 1) is folded into the filters first, then every output channel c is
 // scaled so that its largest |w| maps to 448: code = e4m3(w * in_scale / osc[c]), osc[c] = max|w * in_scale| / 448.
+// IEEE binary16 bits -> float (exact)
+float h2f(uint16_t h)
+{
+    const int e = (h >> 10) & 31, m = h & 1023;
+    float v = e == 0 ? ldexpf((float)m, -24) : e == 31 ? (m ? NAN : INFINITY) : ldexpf((float)(m | 1024), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
 void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
-               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics)
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics, bool split)
 {
     const int n = L.filters, k = L.size, cin = L.cin;
     bias.assign(L.cout_pad, 0.f); osc.assign(L.cout_pad, 1.f);
@@ -83,10 +91,21 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int
                 row[(size_t)ci * k * k + t] = v; amax = std::max(amax, fabsf(v));
             }
         if (wdt == DT_FP8) osc[o] = amax > 0.f ? amax / FP8_MAX : 1.f;
+        const int kc = conv_kchunk(L.cin_pad, wdt);                              // K order: see conv_igemm.hip `stage`
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < k * k; ++t) {
                 const float v = row[(size_t)ci * k * k + t];
-                const int kc = conv_kchunk(L.cin_pad, wdt);                              // K order: see conv_igemm.hip `stage`
+                if (split) {
+                    // split fp16 (YOLO_FP16X2): the kernel walks 3 * Cp input 'channels' hi | lo | hi; the filter row holds W_hi | W_hi | W_lo
+                    const int Cp = L.cin_pad / 3;
+                    const uint16_t h = f2h(v); const uint16_t l = f2h(v - h2f(h));
+                    for (int blk = 0; blk < 3; ++blk) {
+                        const int cv = blk * Cp + ci;
+                        const size_t idx = (size_t)o * L.kpad + ((size_t)(cv / kc) * k * k + t) * kc + cv % kc;
+                        memcpy(&wbuf[idx * 2], blk < 2 ? &h : &l, 2);
+                    }
+                    continue;
+                }
                 const size_t idx = (size_t)o * L.kpad + ((size_t)(ci / kc) * k * k + t) * kc + ci % kc;     // t = kh * k + kw
                 if (wdt == DT_F32) memcpy(&wbuf[idx * 4], &v, 4);
                 else if (wdt == DT_FP8) wbuf[idx] = f2e4m3(v / osc[o]);
@@ -231,7 +250,7 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
                             wperm[(((size_t)o * 32 + (dy * 2 + dx) * 8 + ch) * 4 + a4) * 4 + b4] = w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw]; } }
             w = wperm.data();
         }
-        pack_conv(*PL, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics);
+        pack_conv(*PL, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics, c->split());
         HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));

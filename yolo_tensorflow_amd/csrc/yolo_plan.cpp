@@ -86,13 +86,14 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
                 }
             }
             L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
+            if (c->split()) L.cin_pad *= 3;                     // the conv kernel's view of a split tensor: 3 * Cp channels (hi | lo | hi)
             L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
             if (L.s2d7) { L.cin_pad = 32; L.kpad = 16 * 32; }          // 4x4 taps x (2x2 positions x 8 padded channels)
             H = (H + 2 * L.pad - L.size) / L.stride + 1; W = (W + 2 * L.pad - L.size) / L.stride + 1; C = L.filters;
             c->conv_flops += 2.0 * L.size * L.size * L.cin * L.filters * (double)H * W;
             c->weights_count += (size_t)L.filters * (L.bn ? 4 : 1) + (size_t)L.filters * L.cin * L.size * L.size;
         } else if (s.type == "connected") {
-            if (c->dtype == YOLO_FP8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [connected] is not served in the fp8 configuration", i);
+            if (c->dtype == YOLO_FP8 || c->split()) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [connected] is not served in the fp8 / split-fp16 configurations", i);
             if (opt_i(s, "batch_normalize", 0)) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: batch-normalised [connected]", i);
             L.type = L_CONV; L.fc = true; L.fc_h = H; L.fc_w = W; L.fc_c = C;
             L.filters = opt_i(s, "output", 1); L.size = 1; L.stride = 1; L.pad = 0; L.bn = 0;
@@ -107,7 +108,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             H = 1; W = 1; C = L.filters;
         } else if (s.type == "local") {
             // locally connected (DN/local_layer.c; darknet's own yolov1.cfg): `pad` is a flag AND the im2col pad amount (:10-24, :103)
-            if (c->dtype == YOLO_FP8) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] is not served in the fp8 configuration", i);
+            if (c->dtype == YOLO_FP8 || c->split()) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] is not served in the fp8 / split-fp16 configurations", i);
             L.type = L_LOCAL; L.filters = opt_i(s, "filters", 1); L.size = opt_i(s, "size", 1); L.stride = opt_i(s, "stride", 1); L.pad = opt_i(s, "pad", 0);
             if (L.pad != 0 && L.pad != 1) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: [local] pad must be 0 or 1", i);
             // pad=1 pads by ONE pixel whatever the size (DN/local_layer.c:103 im2col) while the output size assumes size / 2 (:10-24): they only agree for 3x3
@@ -201,7 +202,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) for (int j : c->layers[i].in) if (j >= 0) uses[j]++;
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type == L_SHORTCUT && !c->keep_layers) {
+        if (L.type == L_SHORTCUT && !c->keep_layers && !c->split()) {      // (split fp16: the shortcut is its own launch, k_add_split)
             Layer &P = c->layers[i - 1];
             if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1 && (L.in[1] < 0 || c->layers[L.in[1]].store_dt == P.store_dt)) { P.residual_from = L.in[1]; L.noop = true; }
         }
@@ -266,7 +267,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         int off = 0;
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
-            bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
+            bool ok = !c->split() && j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&      // (split fp16: a concatenation is copied, block by block)
                       c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % gran_of(L.store_dt) == 0) && (off % gran_of(L.store_dt) == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
@@ -283,7 +284,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.type == L_ROUTE && L.in.size() >= 2) {
-            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (c->split() ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
         }
     }
     for (int i = 0; i < NL; ++i) {
@@ -294,7 +295,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
-        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (c->split() ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
     }
     // a conv whose shortcut was fused writes the shortcut layer's tensor
     for (int i = 0; i + 1 < NL; ++i) {
@@ -352,13 +353,26 @@ int allocate(yolo_ctx *c)
         L.out.ptr = (char *)c->phys[s.phys] + (size_t)L.ch_off * dt_size(s.dt);
     }
     // network input: 3 real channels padded to 8
-    c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : c->dtype == YOLO_FP16 ? DT_F16 : DT_BF16;            // fp8 mode keeps the image in bf16
-    size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * 8 * dt_size(c->input.dt);
+    c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : (c->dtype == YOLO_FP16 || c->split()) ? DT_F16 : DT_BF16;            // fp8 mode keeps the image in bf16
+    const int in_stride = c->split() ? 24 : 8;                 // split fp16: hi | lo | hi blocks of the 8 padded channels
+    size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * in_stride * dt_size(c->input.dt);
     HIPCK(c, hipMalloc(&c->input.ptr, in_bytes)); HIPCK(c, hipMemsetAsync(c->input.ptr, 0, in_bytes, c->stream));      // defined even if a timing pass runs before any image was staged
-    c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = 8;
+    c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = in_stride;
+    if (c->split()) {
+        // fp32 staging for the layers that run in fp32 between a join and a split (input conversion, upsample, pooling, reorg)
+        size_t cap = (size_t)c->max_batch * c->in_h * c->in_w * 8;
+        for (auto &L : c->layers) if (L.type == L_UPSAMPLE || L.type == L_MAXPOOL || L.type == L_REORG) {
+            const TView in = view_of(c, L.in[0]);
+            cap = std::max(cap, (size_t)c->max_batch * in.h * in.w * roundup(in.c, 8));
+            cap = std::max(cap, (size_t)c->max_batch * L.H * L.W * roundup(L.C, 8));
+        }
+        c->f32_cap = cap;
+        HIPCK(c, hipMalloc((void **)&c->d_f32a, cap * 4)); HIPCK(c, hipMalloc((void **)&c->d_f32b, cap * 4));
+    }
     HIPCK(c, hipMalloc(&c->d_zeros, 4096)); HIPCK(c, hipMemsetAsync(c->d_zeros, 0, 4096, c->stream));
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer &L = c->layers[i];
+        if (L.s2d7 && c->split()) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %zu: a 7x7 / stride 2 first conv is not served in the split-fp16 configuration", i);
         if (L.s2d7) {
             c->s2d = c->input; c->s2d.h = c->in_h / 2; c->s2d.w = c->in_w / 2; c->s2d.c = 32; c->s2d.stride = 32;
             HIPCK(c, hipMalloc(&c->s2d.ptr, (size_t)c->max_batch * c->s2d.h * c->s2d.w * 32 * dt_size(c->s2d.dt)));

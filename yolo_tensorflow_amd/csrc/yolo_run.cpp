@@ -18,6 +18,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     TView in = view_of(c, L.in[0]);
     a.in = in.ptr; a.in_stride = in.stride; a.wt = L.d_w; a.bias = L.d_b;
     a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_dt = L.out.dt; a.in_dt = L.in_dt; a.oscale = L.d_sc;
+    if (c->split()) { a.split = 1; a.out_blk = L.out.dt == DT_F32 ? 0 : L.out.stride / 3; }      // split fp16: 16-bit outputs go out as hi | lo | hi blocks
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
     if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
@@ -41,6 +42,35 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     if (L.s2d7) { a.in = c->s2d.ptr; a.in_stride = 32; a.H = c->s2d.h; a.W = c->s2d.w; a.ksize = 4; a.stride = 1; a.pad = 2; }   // see pack_s2d7
     conv_finalize(a);
     return a;
+}
+
+// split fp16: the untuned choice among the instantiated shapes (conv_cfg_split_ok)
+static int split_default_cfg(const ConvArgs &a)
+{
+    const long M = (long)a.N * a.Ho * a.Wo;
+    if (a.Cout <= 32) return 4;
+    if (a.Cout <= 64) return M >= 65536 ? 8 : 6;
+    const long tiles128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (tiles128 < 512) return M < 8192 && tiles128 < 128 ? 14 : 2;
+    return 0;
+}
+
+// split fp16: a layer that moves or interpolates values runs in fp32 between a join (hi + lo) and a split
+static int via_f32(yolo_ctx *c, const Layer &L, int n, int kind)
+{
+    hipStream_t s = c->stream;
+    const TView in = view_of(c, L.in[0]);
+    const int cpi = in.stride / 3, cpo = L.out.stride / 3;
+    const size_t pin = (size_t)n * in.h * in.w, pout = (size_t)n * L.H * L.W;
+    if (pin * cpi > c->f32_cap || pout * cpo > c->f32_cap) return fail(c, YOLO_ERR_STATE, "internal: fp32 staging too small");
+    HIPCK(c, launch_split_to_f32(in.ptr, cpi, c->d_f32a, cpi, pin, s));
+    TView a; a.ptr = c->d_f32a; a.n = n; a.h = in.h; a.w = in.w; a.c = cpi; a.stride = cpi; a.dt = DT_F32;
+    TView b; b.ptr = c->d_f32b; b.n = n; b.h = L.H; b.w = L.W; b.c = cpo; b.stride = cpo; b.dt = DT_F32;
+    if (kind == 0) HIPCK(c, launch_upsample2x(a, b, c->semantics == YOLO_SEM_TF, s));
+    else if (kind == 1) HIPCK(c, launch_maxpool(a, b, L.psize, L.pstride, L.ppad, s));
+    else HIPCK(c, launch_reorg(a, b, L.pstride, c->semantics == YOLO_SEM_DARKNET, s));
+    HIPCK(c, launch_split_from_f32(c->d_f32b, cpo, L.out.ptr, cpo, pout, s));
+    return YOLO_OK;
 }
 
 int run_layer(yolo_ctx *c, int i, int n)
@@ -91,7 +121,12 @@ int run_layer(yolo_ctx *c, int i, int n)
             if (conv_halo_ok(h)) { HIPCK(c, launch_conv_halo(h, s)); break; }
             // window over 2 GiB (very large batches): the tiled kernel below checks its own window
         }
-        if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
+        if (c->split()) {
+            int cfg = L.tile_cfg >= 0 && conv_cfg_split_ok(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
+            if (conv_cfg_is_halo(cfg) && (!conv_halo13_ok(a) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
+            HIPCK(c, launch_conv_bf16(a, cfg, s));
+        }
+        else if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
             if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
@@ -106,7 +141,9 @@ int run_layer(yolo_ctx *c, int i, int n)
         }
         break; }
     case L_SHORTCUT:
-        if (!L.noop) {
+        if (!L.noop && c->split()) {
+            HIPCK(c, launch_add_split(view_of(c, L.in[0]).ptr, view_of(c, L.in[1]).ptr, L.out.ptr, L.out.stride / 3, (size_t)n * L.H * L.W, s));
+        } else if (!L.noop) {
             float sa = 1.f, sb = 1.f, so = 1.f;
             if (c->dtype == YOLO_FP8) { sa = c->eff_scale[L.in[0]]; sb = c->eff_scale[L.in[1]]; so = 1.f / c->eff_scale[i]; }
             HIPCK(c, launch_add(nview(view_of(c, L.in[0])), nview(view_of(c, L.in[1])), nview(L.out), s, sa, sb, so));
@@ -117,13 +154,23 @@ int run_layer(yolo_ctx *c, int i, int n)
             TView src = nview(view_of(c, L.copy_inputs[k])); TView dst = nview(L.out);
             dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * dt_size(dst.dt); dst.c = src.c;
             if (src.c % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of %d channels", src.c);
+            if (c->split()) {        // three blocks of the source into the three blocks of the concatenation
+                const int cps = src.stride / 3, cpd = L.out.stride / 3;
+                for (int blk = 0; blk < 3; ++blk) {
+                    TView sv = src, dv = nview(L.out);
+                    sv.ptr = (char *)src.ptr + (size_t)blk * cps * 2; sv.c = cps;
+                    dv.ptr = (char *)L.out.ptr + ((size_t)blk * cpd + L.copy_offsets[k]) * 2; dv.c = cps;
+                    HIPCK(c, launch_copy(sv, dv, s));
+                }
+                continue;
+            }
             HIPCK(c, launch_copy(src, dst, s));
         }
         break;
     case L_LOCAL: HIPCK(c, launch_local(nview(view_of(c, L.in[0])), nview(L.out), L.d_w, L.d_b, L.size, L.stride, L.pad, L.act, s)); break;
-    case L_UPSAMPLE: HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
-    case L_MAXPOOL: HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
-    case L_REORG: HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
+    case L_UPSAMPLE: if (c->split()) { if (int r = via_f32(c, L, n, 0)) return r; break; } HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
+    case L_MAXPOOL: if (c->split()) { if (int r = via_f32(c, L, n, 1)) return r; break; } HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
+    case L_REORG: if (c->split()) { if (int r = via_f32(c, L, n, 2)) return r; break; } HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
     case L_DETECT: {
         const Layer &P = c->layers[i - 1];
         HIPCK(c, launch_decode_v1((const float *)P.out.ptr, P.out.stride, n, L.side, L.na, L.classes, L.sqr, c->d_det, c->rows, L.row_off,
@@ -185,6 +232,11 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     c->stem_u8 = nullptr;
     if (fmt == YOLO_IMG_U8 && c->layers.size() > 1 && c->layers[1].stem && !getenv("YOLO_NO_STEM_U8") && (double)npix * 3 < 2147483648.0 && ((size_t)src & 3) == 0) {
         c->stem_u8 = (const uint8_t *)src; c->stem_scale = scale; c->stem_u8_n = n;
+        return YOLO_OK;
+    }
+    if (c->split()) {        // the image in fp32 (exact for uint8 pixels x scale up to fp32 rounding), then split pairs
+        HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->d_f32a, DT_F32, 8, c->stream, c->in_mul, c->in_add));
+        HIPCK(c, launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, npix, c->stream));
         return YOLO_OK;
     }
     HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream, c->in_mul, c->in_add));
@@ -283,7 +335,9 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
         HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
     }
     c->stem_u8 = nullptr;
-    hipError_t e = launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
+    hipError_t e = c->split() ? launch_resize_u8(src, h, w, c->in_h, c->d_f32a, DT_F32, 8, 8, c->stream, c->in_mul, c->in_add)
+                              : launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
+    if (e == hipSuccess && c->split()) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -303,7 +357,8 @@ int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h
         HIPCK(c, hipMemcpyAsync(tmp, image_chw, (size_t)h * w * 3 * 4, hipMemcpyHostToDevice, c->stream)); src = (const float *)tmp;
     }
     c->stem_u8 = nullptr;
-    hipError_t e = launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
+    hipError_t e = c->split() ? launch_letterbox_chw(src, w, h, c->in_h, c->d_f32a, DT_F32, 8, c->stream) : launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
+    if (e == hipSuccess && c->split()) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "letterbox: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -464,13 +519,14 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     auto valid = [&](const Layer &L, int cfg) {
         if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
+        if (c->split()) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo13_ok(a) && a.out_dt != DT_F32));
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
     for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = c->split() ? split_default_cfg(a) : conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-BF16, FP32, FP8, FP16 = 0, 1, 2, 3
+BF16, FP32, FP8, FP16, FP16X2 = 0, 1, 2, 3, 4
 SEM_TF, SEM_DARKNET = 0, 1
 DECODE_RATIO, DECODE_PIXEL = 0, 1
 HOST, DEVICE = 0, 1
