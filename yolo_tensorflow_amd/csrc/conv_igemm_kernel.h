@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // everybody's have, and nobody reads the previous chunk's halo tile any more (the next chunk's pieces overwrite it)
             if constexpr (NS == 2) wait_vmcnt<0>(); else wait_vmcnt_rt<(NS - 2) * (LB + 1)>(NS == 3 ? f_ops1 : f_ops1 + f_ops2);
             block_barrier();
-            if (wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * 32 / 64);      // half a K-step behind the SIMD's other wave
+            if (NC == 8 && wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * 32 / 64);      // half a K-step behind the SIMD's other wave (eight-wave forms: two waves per SIMD)
             s1 = stamp();
             issue();
             s2 = stamp();
