@@ -17,6 +17,11 @@ python3 bench.py --dtype fp8 --no-cpu-baseline --parity-images 2 > "$OUT/bench_f
 python3 bench.py --dtype mixed --no-cpu-baseline --parity-images 2 > "$OUT/bench_mixed.json" 2> "$OUT/bench_mixed.err"
 python3 bench.py --dtype fp16 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp16.json" 2> "$OUT/bench_fp16.err"
 python3 bench.py --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"
+python3 bench.py --dtype fp16x2 --steps 20 --warmup 5 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp16x2.json" 2> "$OUT/bench_fp16x2.err"
+# kernel-level traces of the other storage types (per-kernel calls / average duration: the rooflines of those lines can be recomputed from them)
+for DT in fp8 mixed fp16x2; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$DT" -o bench -- python3 bench.py --dtype $DT --no-cpu-baseline --parity-images 0 --steps 20 --warmup 5 > "$OUT/bench_${DT}_under_rocprof.json" 2> "$OUT/stats_$DT.err"
+done
 else
 python3 bench.py $W --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
 fi
