@@ -47,3 +47,22 @@ def test_bench_force_dist_path(hiplib, capsys, monkeypatch):
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+def test_bench_strong_scaling_and_parity_fields(hiplib, capsys, monkeypatch):
+    """bench.py --global-batch (strong scaling: a fixed global batch split over the ranks) through the same forced distributed path, and the
+    `parity` object of the line: the timed configuration's boxes against the fp32 oracle on the first images of the timed batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("torch does not see the GPU")
+    monkeypatch.setenv("BENCH_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_PORT", str(31700 + os.getpid() % 1000))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--global-batch", "8", "--parity-images", "1"])
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.main()
+    out = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 8 and "global batch=8" in out["config"]["workload"]
+    assert out["value"] > 0 and abs(out["value"] - 8 * 1e3 / out["ms_per_step"]) / out["value"] < 0.01
+    p = out["parity"]
+    assert p["images"] == 1 and p["candidates"] > 20 and p["min_iou"] >= 0.99 and p["max_dscore"] <= 1e-2 and p["lost"] == 0

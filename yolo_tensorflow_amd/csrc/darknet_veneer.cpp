@@ -50,7 +50,7 @@ bool open_ctx(network *net)
     yolo_config yc; memset(&yc, 0, sizeof yc);
     const char *dt = getenv("DARKNET_HIP_DTYPE");
     yc.struct_size = sizeof yc; yc.cfg_text = net->cfg_text.c_str(); yc.max_batch = net->batch;
-    yc.dtype = dt && !strcmp(dt, "fp32") ? YOLO_FP32 : dt && !strcmp(dt, "fp16") ? YOLO_FP16 : YOLO_BF16;
+    yc.dtype = dt && !strcmp(dt, "fp32") ? YOLO_FP32 : dt && !strcmp(dt, "fp16") ? YOLO_FP16 : dt && !strcmp(dt, "fp16x2") ? YOLO_FP16X2 : YOLO_BF16;
     yc.semantics = YOLO_SEM_DARKNET; yc.decode = YOLO_DECODE_RATIO; yc.device = g_device;
     char err[512] = {0};
     net->ctx = yolo_create(&yc, err, sizeof err);
