@@ -17,7 +17,7 @@ from test_gpu_tuned import box_deviation
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.abspath(__file__))
-SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 33, 34, 49)
+SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 25, 26, 27, 28, 33, 34, 49)
 SPLIT_HALO = (40, 41, 43)
 
 
@@ -53,6 +53,12 @@ def test_conv_fp16x2_vs_emulation_and_tile_shapes(hiplib, shape):
         assert np.abs(got - exact).max() <= 2e-5 * np.abs(exact).max()
         for cfg in SPLIT_CFGS + (SPLIT_HALO if (k == 3 and st == 1 and h % 13 == 0 and cin % 64 == 0) else ()):
             assert np.array_equal(hiplib.op_conv2d(x, w, b, stride=st, act=1, residual=r, dtype=hiplib.FP16X2, tile_cfg=cfg), got), (shape, cfg)
+        if r is not None:       # the shortcut folded into the conv's epilogue == the separate k_add_split launch, bit for bit
+            os.environ["YOLO_SPLIT_UNFUSED"] = "1"
+            try:
+                assert np.array_equal(hiplib.op_conv2d(x, w, b, stride=st, act=1, residual=r, dtype=hiplib.FP16X2), got), shape
+            finally:
+                del os.environ["YOLO_SPLIT_UNFUSED"]
     with pytest.raises(hiplib.YoloError, match="not instantiated"):
         hiplib.op_conv2d(x, w, b, stride=st, act=1, dtype=hiplib.FP16X2, tile_cfg=17)
 
@@ -91,6 +97,12 @@ def test_fp16x2_network_vs_emulation_every_layer(hiplib, name, size, sem):
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 2e-5 * scale, (name, sem, i, s["type"], float(np.abs(got - want).max() / scale))
         assert np.abs(got - o32[i]).max() <= 1e-4 * np.abs(o32[i]).max(), (name, sem, i)
+    det_unfused = eng.forward(img)
+    eng.close()
+    # the production plan (shortcuts folded into the conv epilogues) gives the same decoded tensor, bit for bit
+    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.FP16X2, semantics=hiplib.SEM_TF if sem == "tf" else hiplib.SEM_DARKNET)
+    eng.set_weights(flat)
+    assert np.array_equal(eng.forward(img), det_unfused)
     eng.close()
 
 

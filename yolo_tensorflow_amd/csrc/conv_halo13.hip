@@ -57,7 +57,7 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
     if (!conv_halo13_ok(a)) return hipErrorInvalidValue;
     const bool f8 = a.in_dt == DT_FP8;
     if (a.split) {        // split fp16 storage (YOLO_FP16X2): the free-running forms with the two-pass epilogue
-        if (a.in_dt != DT_F16 || a.out_dt != DT_F16 || a.res || a.w2) return hipErrorInvalidValue;
+        if (a.in_dt != DT_F16 || a.out_dt != DT_F16 || a.w2) return hipErrorInvalidValue;
         switch (cfg) {
         case 40: return launch_h<8, 2, 0, 2, true, 2, true, true>(a, s);
         case 41: return launch_h<8, 1, 0, 2, true, 2, true, true>(a, s);

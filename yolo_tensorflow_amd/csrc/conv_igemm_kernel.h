@@ -165,8 +165,9 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // variant lands on ~1.45 PFLOP/s, the rate the chip sustains on random bf16 operands once its clock management has reacted (the
 // CDNA4 guide's 'DVFS give-back': a cycle saved in an MFMA-dense main loop comes back partly as a lower clock).)
 // SPLIT (H16 only; YOLO_FP16X2): 16-bit outputs are stored as split fp16 pairs -- hi = f16(v) into channel blocks 0 and 2, lo = f16(v - hi)
-// into block 1 (blocks a.out_blk elements apart) -- by a second pass of the epilogue's LDS tile; the K loop is the ordinary fp16 one, run over
-// the 3 x Cin 'channels' hi | lo | hi of the input against filter rows W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
+// into block 1 (blocks a.out_blk elements apart) -- by an epilogue of its own that stages the tile in LDS as fp32, half its channels at a time,
+// and folds the shortcut; the K loop is the ordinary fp16 one, run over the 3 x Cin 'channels' hi | lo | hi of the input against filter rows
+// W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
 template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
@@ -725,7 +726,96 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         const unsigned off = __umul24(rel, sb) + (unsigned)cc * 16u;
         return ok ? off : OOB_OFFSET;
     };
-    if (a.out_dt != DT_F32) {
+    if (SPLIT && a.out_dt != DT_F32) {
+        // ---- split fp16 pairs (YOLO_FP16X2): the tile goes through LDS as FP32, one half of its channels at a time (the same LDS footprint
+        //      as the 16-bit tile), and leaves as 16-byte pieces of eight channels: v -> hi = f16(v), lo = f16(v - hi) into blocks 0 / 1 / 2
+        //      (hi | lo | hi) of the pixel, `out_blk` elements apart.  A fused shortcut is exactly the separate launch's arithmetic
+        //      (k_add_split): the conv's own pair is formed first, then (f_hi + f_lo) + (x_hi + x_lo) in fp32, split again. ----
+        if constexpr (SPLIT) {
+        constexpr int HC = BC / 2, RS4 = HC * 4 + 16, NT = 64 * NTOT;
+        static_assert(!SPLIT || HC % 16 == 0, "a 16-channel sub-tile belongs to one half");
+        constexpr int CPRH = HC / 8, NITH = (BP * CPRH + NT - 1) / NT;       // 8-channel pieces per row of a half / per thread
+        const char *__restrict__ res = (const char *)a.res;
+        const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc((char *)a.out + (m0 * a.out_stride + (size_t)ct * BC) * 2);
+        const __amdgpu_buffer_rsrc_t rs_res = tile_rsrc(res ? res + (m0 * a.res_stride + (size_t)ct * BC) * 2 : nullptr);
+        const unsigned out_sb = a.out_stride * 2u, res_sb = a.res_stride * 2u, oblk = (unsigned)a.out_blk * 2u, rblk = (unsigned)a.res_blk * 2u;
+        int prow4[HALO ? TP : 1];
+        if constexpr (HALO) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) prow4[j] = (int)((perm_wr[j / 4] >> (8 * (j % 4))) & 0xffu) * RS4;
+        }
+        f32x4 bvs[TC];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) bvs[i] = is_consumer ? *(const f32x4 *)(a.bias + ct * BC + (wci * TC + i) * 16 + lq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
+        auto split8 = [](const float *v, u32x4_t &H, u32x4_t &L) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t h = pack16x2<true>(v[2 * q], v[2 * q + 1]);
+                H[q] = h; L[q] = pack16x2<true>(v[2 * q] - unpack16_lo<true>(h), v[2 * q + 1] - unpack16_hi<true>(h));
+            }
+        };
+        static_for<2>([&](auto halfc) {
+            constexpr int HALF = decltype(halfc)::value;
+            // this thread's shortcut pieces of the half (hi and lo blocks), requested ahead of the barrier and the LDS pass
+            u32x4_t rh[NITH], rl[NITH];
+            unsigned offs[NITH];
+#pragma unroll
+            for (int it = 0; it < NITH; ++it) {
+                int row, cc;
+                unsigned off = piece_off(tid + it * NT, CPRH, 8, out_sb, row, cc);
+                if (ct * BC + HALF * HC + cc * 8 >= a.Cout || ((BP * CPRH) % NT != 0 && tid + it * NT >= BP * CPRH)) off = OOB_OFFSET;
+                offs[it] = off == OOB_OFFSET ? OOB_OFFSET : off + (unsigned)(HALF * HC * 2);
+                if (res) {
+                    int r2, c2;
+                    unsigned ro = piece_off(tid + it * NT, CPRH, 8, res_sb, r2, c2);
+                    ro = off == OOB_OFFSET ? OOB_OFFSET : ro + (unsigned)(HALF * HC * 2);
+                    rh[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0);
+                    rl[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro == OOB_OFFSET ? OOB_OFFSET : ro + rblk, 0, 0);
+                }
+            }
+            block_barrier();                                  // the stages (half 0) / the previous half's tile (half 1) are no longer read
+            if (is_consumer)
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const int chl = (wci * TC + i) * 16 + lq * 4;     // channel within the tile
+                if (chl / HC != HALF) continue;                   // (wave- and sub-tile-uniform)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    f32x4 v = acc[i][j] + bvs[i];
+                    const f32x4 t = v * slope;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], t[q]);
+                    *(f32x4 *)(smem + (HALO ? prow4[j] : ((wpi * TP + j) * 16 + l15) * RS4) + (chl - HALF * HC) * 4) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            block_barrier();
+#pragma unroll
+            for (int it = 0; it < NITH; ++it) {
+                if ((BP * CPRH) % NT != 0 && tid + it * NT >= BP * CPRH) continue;
+                const int c = tid + it * NT, row = c / CPRH, cc = c - row * CPRH;
+                const f32x4 v0 = *(const f32x4 *)(smem + row * RS4 + cc * 32), v1 = *(const f32x4 *)(smem + row * RS4 + cc * 32 + 16);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                u32x4_t H, L;
+                split8(v, H, L);
+                if (res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float f0 = unpack16_lo<true>(H[q]) + unpack16_lo<true>(L[q]), f1 = unpack16_hi<true>(H[q]) + unpack16_hi<true>(L[q]);
+                        const float x0 = unpack16_lo<true>(rh[it][q]) + unpack16_lo<true>(rl[it][q]), x1 = unpack16_hi<true>(rh[it][q]) + unpack16_hi<true>(rl[it][q]);
+                        v[2 * q] = f0 + x0; v[2 * q + 1] = f1 + x1;
+                    }
+                    split8(v, H, L);
+                }
+                const unsigned off = offs[it];
+                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off, 0, 0);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
+                __builtin_amdgcn_raw_buffer_store_b128(L, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + oblk, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + 2u * oblk, 0, 0);
+            }
+        });
+        }
+    } else if (a.out_dt != DT_F32) {
         // bf16 / fp8 output: scale + bias + activation in registers, then the tile goes through LDS (as bf16) so that
         // global stores (and the residual loads) are 16 B per lane along the channel axis -- whole 128-B lines per
         // pixel instead of 16 scattered 32-B pieces per store instruction (row-per-lane dwordx2 stores are
@@ -779,9 +869,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         // writes remain behind it.  The stamped build moved 1 300 cycles in front of the barrier and took 100 off the phase behind it: that
         // phase is the LDS store path -- 176 ds_write_b64 per wave pair at ~12 cycles each -- not the arithmetic; the step got 1.7 % slower.)
         const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
-        // accumulators -> 16-bit tile in LDS.  LOW (SPLIT only): the low halves of the split pairs, lo = f16(v - f32(f16(v)))
-        auto fill_tile = [&](auto lowc) {
-            constexpr bool LOW = decltype(lowc)::value;
+        {
             if (is_consumer)
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
@@ -798,18 +886,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     uint2 pk;
                     pk.x = pack16x2<H16>(v[0], v[1]);
                     pk.y = pack16x2<H16>(v[2], v[3]);
-                    if constexpr (LOW) {
-                        pk.x = pack16x2<H16>(v[0] - unpack16_lo<H16>(pk.x), v[1] - unpack16_hi<H16>(pk.x));
-                        pk.y = pack16x2<H16>(v[2] - unpack16_lo<H16>(pk.y), v[3] - unpack16_hi<H16>(pk.y));
-                    }
                     *(uint2 *)(smem + (HALO ? prow[j] : ((wpi * TP + j) * 16 + l15) * RS) + chl * 2) = pk;
                     if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (one straight-line block of TC * TP sub-tiles otherwise)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             block_barrier();
-        };
-        fill_tile(std::false_type{});
+        }
         if (DIAG) te2 = stamp();
         // fused 1x1 tail (bf16): eight consumer waves = T2G groups of T2W 16-channel tiles x T2P parts of the tile's pixel sub-tiles
         // (T2W = 2 in the halo forms, 1 in the tiled 8-wave shape, which has no registers for 64 of filter fragments).  A wave's filter
@@ -921,8 +1004,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // pieces to COMPLETE -- five memory operations in flight per wave instead of all of them.  (The tail's write-back stays a
             // run-time branch: an LDS store does not touch vmcnt, and a third copy of the loop costs registers.)
             const bool tail_wb = TAIL_OK && EB == 2 && a.w2;
-            // o1: byte offset added to every piece's address; o2 (SPLIT): a second address every piece is ALSO stored at, or ~0u
-            auto store_tile = [&](auto resc, const unsigned o1, const unsigned o2) {
+            auto store_tile = [&](auto resc) {
                 constexpr bool RES = decltype(resc)::value;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -942,19 +1024,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         }
                         if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off + o1, 0, 0);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
-                    if constexpr (SPLIT) if (o2 != ~0u) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off + o2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
                 }
             };
-            if constexpr (SPLIT) {
-                // the tile in LDS holds the high halves: blocks 0 and 2 of every pixel; then the low halves go through the same tile into block 1
-                const unsigned blk = (unsigned)a.out_blk * 2u;
-                store_tile(std::false_type{}, 0u, 2u * blk);
-                block_barrier();                                  // everybody has read its pieces of the hi tile
-                fill_tile(std::true_type{});
-                store_tile(std::false_type{}, blk, ~0u);
-            }
-            else if (res) store_tile(std::true_type{}, 0u, ~0u); else store_tile(std::false_type{}, 0u, ~0u);
+            if (res) store_tile(std::true_type{}); else store_tile(std::false_type{});
             if (DIAG) te3 = stamp();
             if constexpr (TAIL_OK && EB == 2) if (a.w2) {
                 // ---- fused 1x1 tail: out2[pixel][C2] = act2(W2 . tile[pixel][0..BC) + b2) on the finished tile in LDS.  Wave (t2g, t2p)

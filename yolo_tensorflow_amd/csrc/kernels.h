@@ -33,7 +33,7 @@ struct ConvArgs {
     // filters), `out_inv_scale` = 1 / scale of the output tensor, `res_scale` = scale of the residual tensor.
     int in_dt;
     int split;                           // 1: split fp16 output (YOLO_FP16X2): every 16-bit output value is stored as hi | lo | hi in three blocks `out_blk` elements apart
-    int out_blk;
+    int out_blk, res_blk;                // (res_blk: the same for the shortcut source)
     const float *oscale;                 // [Cout_pad] or nullptr (== 1)
     float out_inv_scale, res_scale;
     float mid_scale, mid_inv_scale;      // fused shortcut: this conv's own output scale (quantised before the add)

@@ -53,12 +53,16 @@ static int op_conv2d_split(const float *x, int n, int h, int w, int cin, const f
     conv_finalize(a);
     int cfg = tile_cfg >= 0 ? tile_cfg : 6;
     if (!conv_cfg_split_ok(cfg) || (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
-    if (!S.ok(launch_conv_bf16(a, cfg, S.s))) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
+    // the shortcut: fused into the conv's epilogue, or (YOLO_SPLIT_UNFUSED, the parity tests' A/B) as the separate launch a keep_layers plan makes
+    void *d_r = nullptr;
     if (residual) {
-        float *d_r32 = (float *)S.upload(residual, pout * cout * 4); void *d_r = S.alloc(pout * 3 * cout * 2);
+        float *d_r32 = (float *)S.upload(residual, pout * cout * 4); d_r = S.alloc(pout * 3 * cout * 2);
         if (S.rc) return S.rc;
-        if (!S.ok(launch_split_from_f32(d_r32, cout, d_r, cout, pout, S.s)) || !S.ok(launch_add_split(d_o, d_r, d_o, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
+        if (!S.ok(launch_split_from_f32(d_r32, cout, d_r, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
+        if (!getenv("YOLO_SPLIT_UNFUSED")) { a.res = d_r; a.res_stride = 3 * cout; a.res_blk = cout; }
     }
+    if (!S.ok(launch_conv_bf16(a, cfg, S.s))) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
+    if (residual && !a.res && !S.ok(launch_add_split(d_o, d_r, d_o, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
     if (!S.ok(launch_split_to_f32(d_o, cout, d_o32, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
     S.download(out, d_o32, pout * cout * 4);
     if (S.rc) g_op_err = "conv2d: " + std::string(hipGetErrorString(hipGetLastError()));

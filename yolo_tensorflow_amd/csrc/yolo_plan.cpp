@@ -202,7 +202,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) for (int j : c->layers[i].in) if (j >= 0) uses[j]++;
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
-        if (L.type == L_SHORTCUT && !c->keep_layers && !c->split()) {      // (split fp16: the shortcut is its own launch, k_add_split)
+        if (L.type == L_SHORTCUT && !c->keep_layers) {
             Layer &P = c->layers[i - 1];
             if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1 && (L.in[1] < 0 || c->layers[L.in[1]].store_dt == P.store_dt)) { P.residual_from = L.in[1]; L.noop = true; }
         }

@@ -21,7 +21,7 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     if (c->split()) { a.split = 1; a.out_blk = L.out.dt == DT_F32 ? 0 : L.out.stride / 3; }      // split fp16: 16-bit outputs go out as hi | lo | hi blocks
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
-    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
+    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; a.res_blk = c->split() ? r.stride / 3 : 0; }
     // the tail runs on the producer's operand type: bf16 needs the fragment-order copy of the 1x1 filters (tail_fragments), e4m3 an
     // e4m3-packed 1x1 conv; anything else leaves w2 null and run_layer refuses the plan instead of launching with a null w2f
     if (L.tail_on && L.tail_layer >= 0 && c->layers[L.tail_layer].in_dt == L.in_dt && (L.in_dt == DT_FP8 || c->layers[L.tail_layer].d_wf)) {
