@@ -230,3 +230,23 @@ def test_graph_survives_box_buffer_growth(hiplib):
     for _ in range(3):
         run_graph()                                   # must not replay against the freed buffer
     eng.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp8", "fp16"])
+def test_autotune_runs_and_keeps_results(hiplib, dtype_name):
+    """yolo_autotune itself (bench.py --retune): every tile configuration the dtype's table instantiates is probed in situ, including the
+    fused-1x1-tail pass -- round 4 regression: a tail-capable shape that the e4m3 table does not instantiate must not be proposed there --
+    and whatever plan comes out gives the default plan's decoded tensor bit for bit (104 x 104 input: 13-multiples on every stage, so the
+    halo forms and the tails take part)."""
+    dt = {"bf16": hiplib.BF16, "fp8": hiplib.FP8, "fp16": hiplib.FP16}[dtype_name]
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 416)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    img = np.random.default_rng(3).integers(0, 256, (4, 416, 416, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=4, dtype=dt)
+    eng.set_weights(flat)
+    want = eng.forward(img)
+    eng.autotune(4, 1)
+    plan = eng.get_tile_configs()
+    assert (plan[plan >= 0] % 10000 < hiplib.op_conv_num_cfgs()).all() or (plan == 1000).any()
+    assert np.array_equal(eng.forward(img), want)
+    eng.close()

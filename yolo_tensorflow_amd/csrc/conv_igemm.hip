@@ -327,7 +327,8 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     X(0, 2, 2, 4, 4, 2, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(4, 4, 1, 4, 2, 2, 64, 0)  X(6, 2, 2, 4, 2, 2, 64, 0)    \
     X(8, 4, 1, 4, 4, 2, 64, 0)  X(12, 2, 4, 4, 4, 2, 64, 0) X(14, 2, 2, 2, 2, 2, 64, 0) X(16, 1, 4, 11, 2, 2, 64, 0)  \
     X(17, 1, 4, 11, 4, 2, 64, 0) X(19, 1, 4, 10, 2, 2, 64, 0) X(20, 1, 4, 12, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0) \
-    X(32, 1, 8, 11, 2, 2, 64, 0) X(31, 1, 8, 11, 2, 2, 64, 4) X(33, 1, 4, 11, 2, 3, 64, 0) X(34, 1, 4, 6, 2, 3, 64, 0)
+    X(32, 1, 8, 11, 2, 2, 64, 0) X(31, 1, 8, 11, 2, 2, 64, 4) X(33, 1, 4, 11, 2, 3, 64, 0) X(34, 1, 4, 6, 2, 3, 64, 0) \
+    X(45, 1, 8, 6, 2, 3, 64, 0) X(48, 2, 4, 3, 2, 2, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0) X(51, 2, 4, 2, 2, 3, 64, 0)      /* round 4: the 8-wave / 3-stage shapes */
 bool conv_cfg_fp8_ok(int cfg)
 {
     switch (cfg) {

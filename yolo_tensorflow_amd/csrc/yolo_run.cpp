@@ -586,7 +586,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int i = 0; i < NL; ++i) {
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
-                bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8) && c->layers[L.tail_layer].in_dt == L.in_dt;
+                bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8) && c->layers[L.tail_layer].in_dt == L.in_dt && valid(L, cfg);      // (valid: e.g. a shape the e4m3 table does not instantiate)
                 if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo13_ok(a); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
