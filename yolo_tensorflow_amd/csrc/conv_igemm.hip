@@ -199,7 +199,8 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
 // multiples of 256 rows, cout_pad.)
 #define CONV_CFGS_B(X)                                                                                 \
     X(44, 1, 8, 6, 2, 2, 64, 0) X(45, 1, 8, 6, 2, 3, 64, 0) X(46, 2, 4, 3, 4, 2, 64, 0) X(47, 2, 4, 2, 4, 2, 64, 0)    \
-    X(48, 2, 4, 3, 2, 2, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0) X(50, 1, 8, 4, 2, 3, 64, 0) X(51, 2, 4, 2, 2, 3, 64, 0)
+    X(48, 2, 4, 3, 2, 2, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0) X(50, 1, 8, 4, 2, 3, 64, 0) X(51, 2, 4, 2, 2, 3, 64, 0)    \
+    X(52, 2, 4, 3, 2, 3, 64, 0) X(53, 2, 4, 3, 2, 4, 64, 0)
 // (Tried and dropped, round 4: the free-running halo form with ONE wave per SIMD -- four waves of 176 x 64, 40 % fewer LDS bytes per FLOP
 // than eight of 176 x 32, whose stamped K loop needs 1 708 cycles per K-step against 1 862.  In the network it LOSES: 26x26 layers 0.412 ms
 // against 0.387 for the eleven of them, 52x52 0.495 against 0.460, 13x13 0.307 against 0.289 -- set-up and epilogue are serial in a wave,
