@@ -151,3 +151,28 @@ def test_to_fp8_e4m3_grid_ties_and_saturation():
     q = R.to_fp8_e4m3(x)
     nearest = vals[np.abs(np.abs(x)[:, None].clip(max=448) - vals[None, :]).argmin(1)]
     assert np.all(np.abs(np.abs(q) - np.abs(x).clip(max=448)) <= np.abs(nearest - np.abs(x).clip(max=448)) + 1e-12)
+
+
+def test_split_f16_pairs_and_their_emulated_network():
+    """The oracle's restatement of the device's split-fp16 configuration (no reference counterpart): a pair (hi, lo) of fp16
+    numbers carries a float32 value to 2^-22 relative or 2^-25 absolute (the low half's subnormal quantum), saturates where fp16 does, and a
+    small network run on pairs stays within 1e-5 of the fp32 forward -- three orders of magnitude closer than fp16 storage."""
+    from yolo_tensorflow_amd import darknet_io as IO
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.uniform(-3, 3, 4096), [0.0, 65504.0, -70000.0, 131008.0, 1e-7]]).astype(np.float32)
+    hi, lo = R.split_f16(x)
+    assert np.array_equal(hi, R.to_f16(x)) and np.array_equal(lo, R.to_f16(x - hi))
+    err = np.abs((hi + lo) - x)
+    ok = np.abs(x) <= 131008
+    assert (err[ok] <= np.maximum(np.abs(x[ok]) * 2.0 ** -22, 2.0 ** -25)).all()
+    assert hi[-3] == -65504.0 and hi[-2] == 65504.0 and lo[-2] == 65504.0            # beyond fp16's range the high half saturates, the low half carries on
+    txt = IO.with_input_size(IO.cfg_text("yolov3-tiny"), 64)
+    secs = R.parse_cfg(txt); flat = IO.synth_weights(IO.parse_cfg(txt), seed=2); params = R.unflatten_weights(flat, secs)
+    img = rng.random((1, 64, 64, 3), dtype=np.float32)
+    h32, _ = R.forward(secs, params, img)
+    hx2, outs = R.forward_f16x2(secs, params, img, collect=True)
+    h16, _ = R.forward(secs, params, img, storage="f16")
+    for (_, a), (_, b), (_, c) in zip(hx2, h32, h16):
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 1e-5 * scale and np.abs(c - b).max() > 20 * np.abs(a - b).max()
+    assert outs[0].shape == (1, 64, 64, 16)
