@@ -1,5 +1,6 @@
 """Race hunt: the tuned production plan (fused stem, halo conv, 1x1 tails, alias-scoped LDS stages) must give bit-identical
-detections on every one of many repeated forwards, eager and graph-replayed, bf16 and fp8."""
+detections on every one of many repeated forwards, eager and graph-replayed, bf16, fp8 and split fp16 (whose epilogue makes two barrier-separated
+passes through one LDS tile)."""
 import sys, os, json
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -8,7 +9,7 @@ N = int(os.environ.get("REPS", "300")); B = 32
 txt = IO.cfg_text("yolov3"); secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 0)
 img = np.random.default_rng(0).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)
 dimg = torch.from_numpy(img).cuda()
-for name, dt in (("bf16", hip.BF16), ("fp8", hip.FP8)):
+for name, dt in (("bf16", hip.BF16), ("fp8", hip.FP8), ("fp16x2", hip.FP16X2)):
     eng = hip.Engine(txt, max_batch=B, dtype=dt)
     eng.set_weights(flat)
     plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_%s.json" % name)
