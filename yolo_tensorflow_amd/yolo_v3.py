@@ -13,7 +13,7 @@ of returning `tf.assign` ops.  All arithmetic runs in libyolo_hip.so -- there is
 import numpy as np
 from . import hip, darknet_io as IO
 
-_BATCH_NORM_EPSILON = 1e-05      # folded into the filters at load time (csrc/yolo_api.cpp pack_conv)
+_BATCH_NORM_EPSILON = 1e-05      # folded into the filters at load time (csrc/yolo_pack.cpp pack_conv)
 _LEAKY_RELU = 0.1
 _ANCHORS = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)]
 
