@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
     const int wc = wave & 3, wp = wave >> 2;             // channel group (32 output channels of the 3x3), pixel half
     char *const lx_ = smem, *const lmid_ = lx_ + CB_X_BYTES, *const lw1_ = lmid_ + CB_MID_BYTES, *const lb1_ = lw1_ + CB_W1_BYTES, *const lb2_ = lb1_ + CB_B1_BYTES, *const lout_ = lb2_ + CB_B2_BYTES;
     const float slope1 = a.act1 == ACT_LEAKY ? 0.1f : 1.f, slope2 = a.act2 == ACT_LEAKY ? 0.1f : 1.f;
-    const int bx = a.W / CB_B, by = a.H / CB_B, per_img = bx * by, nblocks = a.N * per_img;
+    const int bx = (a.W + CB_B - 1) / CB_B, by = (a.H + CB_B - 1) / CB_B, per_img = bx * by, nblocks = a.N * per_img;      // (ragged blocks on the bottom / right edge: their pixels past the image are computed on zeros and never stored)
     const int nt = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
     // ---- once per workgroup: 1x1 filters -> LDS; this wave's slice of the 3x3 filters and its biases -> registers ----
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
             const int px = g >> 4, piece = g & 15;
             const int oy = (px * 5042) >> 16, ox = px - oy * CB_B;
             const unsigned pix = (unsigned)((q.n * a.H + q.y0 + oy) * a.W + q.x0 + ox);
-            rsv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, px < CB_OPIX ? (pix * a.x_stride + piece * 8) * 2 : 0x80000000u, 0, 0);
+            rsv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (px < CB_OPIX && q.y0 + oy < a.H && q.x0 + ox < a.W) ? (pix * a.x_stride + piece * 8) * 2 : 0x80000000u, 0, 0);
         }
         stage_out(1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
             asm volatile("" : "+v"(g));
             const int px = g >> 4, piece = g & 15;
             const int oy = (px * 5042) >> 16, ox = px - oy * CB_B;
-            const bool ok = px < CB_OPIX;
+            const bool ok = px < CB_OPIX && q.y0 + oy < a.H && q.x0 + ox < a.W;
             const unsigned pix = (unsigned)((q.n * a.H + q.y0 + oy) * a.W + q.x0 + ox);
             const cb_u32x4 r = rsv[k];
-            cb_u32x4 o = *(const __attribute__((address_space(3))) cb_u32x4 *)(lout + (ok ? px : 0) * CB_OPITCH + piece * 16);
+            cb_u32x4 o = *(const __attribute__((address_space(3))) cb_u32x4 *)(lout + (px < CB_OPIX ? px : 0) * CB_OPITCH + piece * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb_pk<H16>(cb_lo<H16>(o[e]) + cb_lo<H16>(r[e]), cb_hi<H16>(o[e]) + cb_hi<H16>(r[e]));
             __builtin_amdgcn_raw_buffer_store_b128(o, ro, ok ? (pix * a.out_stride + piece * 8) * 2 : 0x80000000u, 0, 0);
@@ -284,7 +284,10 @@ bool conv_resblock_ok(const BlockArgs &a)
 {
     const double px = (double)a.N * a.H * a.W;
     if (px * a.x_stride * 2.0 >= 2147483648.0 || px * a.out_stride * 2.0 >= 2147483648.0) return false;      // 32-bit buffer offsets below the out-of-range sentinel
-    return (a.dt == DT_BF16 || a.dt == DT_F16) && a.C == CB_C && a.Cmid == CB_M && a.H > 0 && a.W > 0 && a.H % CB_B == 0 && a.W % CB_B == 0 &&
+    // whole 13 x 13 blocks, or ragged ones on the bottom / right edge while they waste no more than 15 % (608 x 608: 152 = 12 * 13 - 4)
+    const long cover = (long)((a.H + CB_B - 1) / CB_B) * ((a.W + CB_B - 1) / CB_B) * CB_B * CB_B;
+    if (a.H <= 0 || a.W <= 0 || cover * 100 > (long)a.H * a.W * 115) return false;
+    return (a.dt == DT_BF16 || a.dt == DT_F16) && a.C == CB_C && a.Cmid == CB_M &&
            a.Kpad1 >= CB_C && a.Kpad2 >= 9 * CB_M && (a.x_stride % 8) == 0 && a.x_stride >= CB_C && (a.out_stride % 8) == 0 && a.out_stride >= CB_C;
 }
 
@@ -294,7 +297,7 @@ hipError_t launch_conv_resblock(const BlockArgs &a, hipStream_t s)
     const bool h16 = a.dt == DT_F16;
     const void *k = h16 ? (const void *)conv_resblock_c128<true> : (const void *)conv_resblock_c128<false>;
     { hipError_t e = conv_opt_in_lds(k, CB_LDS); if (e != hipSuccess) return e; }
-    long blocks = (long)a.N * (a.H / CB_B) * (a.W / CB_B);
+    long blocks = (long)a.N * ((a.H + CB_B - 1) / CB_B) * ((a.W + CB_B - 1) / CB_B);
     if (blocks > 256) blocks = 256;                      // persistent: one workgroup per CU
     if (h16) hipLaunchKernelGGL(conv_resblock_c128<true>, dim3((unsigned)blocks), dim3(64 * CB_NW), CB_LDS, s, a);
     else hipLaunchKernelGGL(conv_resblock_c128<false>, dim3((unsigned)blocks), dim3(64 * CB_NW), CB_LDS, s, a);
