@@ -17,7 +17,7 @@ from test_gpu_tuned import box_deviation
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.abspath(__file__))
-SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 25, 26, 27, 28, 33, 34, 49)
+SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 25, 26, 27, 28, 33, 34, 45, 49, 52)
 SPLIT_HALO = (40, 41, 43)
 
 

@@ -211,7 +211,7 @@ hipError_t launch_conv_c8_direct(const ConvArgs &a, hipStream_t s)
     X(0, 2, 2, 4, 4, 2, 64, 0)  X(2, 2, 2, 2, 4, 2, 64, 0)  X(3, 2, 2, 2, 4, 3, 64, 0)  X(4, 4, 1, 4, 2, 2, 64, 0)    \
     X(6, 2, 2, 4, 2, 2, 64, 0)  X(7, 2, 2, 4, 2, 3, 64, 0)  X(8, 4, 1, 4, 4, 2, 64, 0)  X(14, 2, 2, 2, 2, 2, 64, 0)   \
     X(15, 2, 2, 2, 2, 4, 64, 0) X(16, 1, 4, 11, 2, 2, 64, 0) X(23, 1, 4, 6, 2, 2, 64, 0) X(33, 1, 4, 11, 2, 3, 64, 0) \
-    X(34, 1, 4, 6, 2, 3, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0)                                                              \
+    X(34, 1, 4, 6, 2, 3, 64, 0) X(49, 2, 4, 4, 2, 3, 64, 0) X(45, 1, 8, 6, 2, 3, 64, 0) X(52, 2, 4, 3, 2, 3, 64, 0)                    \
     X(25, 1, 4, 11, 2, 2, 32, 0) X(26, 2, 2, 4, 2, 2, 32, 0) X(27, 4, 1, 4, 2, 2, 32, 0) X(28, 4, 1, 4, 4, 2, 32, 0)    /* 64-byte rows: 3 x 32 = 96 input 'channels' are uniform-tap */
 #define CONV_CFGS_SPLIT_HALO(X) X(40, 1, 8, 11, 2, 2, 64, 0) X(41, 1, 8, 11, 1, 2, 64, 0) X(43, 1, 8, 11, 1, 3, 64, 0)
 bool conv_cfg_split_ok(int cfg)
