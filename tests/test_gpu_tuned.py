@@ -236,7 +236,7 @@ def test_graph_survives_box_buffer_growth(hiplib):
 def test_autotune_runs_and_keeps_results(hiplib, dtype_name):
     """yolo_autotune itself (bench.py --retune): every tile configuration the dtype's table instantiates is probed in situ, including the
     fused-1x1-tail pass -- round 4 regression: a tail-capable shape that the e4m3 table does not instantiate must not be proposed there --
-    and whatever plan comes out gives the default plan's decoded tensor bit for bit (104 x 104 input: 13-multiples on every stage, so the
+    and whatever plan comes out gives the default plan's decoded tensor bit for bit (416 x 416 input, four images: 13-multiples on every stage, so the
     halo forms and the tails take part)."""
     dt = {"bf16": hiplib.BF16, "fp8": hiplib.FP8, "fp16": hiplib.FP16}[dtype_name]
     txt = IO.with_input_size(IO.cfg_text("yolov3"), 416)
