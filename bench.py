@@ -88,6 +88,41 @@ def parity(eng, cfg_txt, flat, imgs_u8, size, thr=0.5, margin=1e-2):
             "threshold": thr, "margin": margin, "seconds": round(time.time() - t0, 1)}
 
 
+def latency_b1(hip, cfg_txt, flat, args, dev, stream, fp8, fp32, fp16, x2, eng1=None, iters=200):
+    """BASELINE.json's metric also names 'p50 ms/image': `p50_ms_per_image` of the main line is the throughput reciprocal (a batch-32 step / 32).
+    This leg is the LATENCY of one image: a context of its own with max_batch 1 (built-in tile plan, or tuned/yolov3_<size>_b1_<dtype>.json
+    when one is committed), the same detect step replayed from its HIP graph, the host synchronised after every image.  Wall clock per
+    call (submission + device + completion) and device time between events, p50 over `iters` calls; outside the timed region."""
+    import torch
+    from yolo_tensorflow_amd import dist as ydist
+    eng = eng1 or hip.Engine(cfg_txt, max_batch=1, dtype=hip.FP8 if fp8 else hip.FP32 if fp32 else hip.FP16 if fp16 else hip.FP16X2 if x2 else hip.BF16,
+                             semantics=hip.SEM_TF, decode=hip.DECODE_RATIO, device=dev.index, stream=stream.cuda_stream)
+    if eng1 is None:
+        eng.set_weights(flat)
+        tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b1_%s.json" % (args.size, "bf16" if fp16 else args.dtype))
+        if os.path.exists(tuned):
+            plan = json.load(open(tuned))
+            if plan.get("num_cfgs") == hip.op_conv_num_cfgs() and len(plan["cfgs"]) == eng.num_layers:
+                eng.set_tile_configs(plan["cfgs"])
+    img = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (1, args.size, args.size, 3), dtype=np.uint8)).to(dev)
+    rec, boxes, counts = ydist.alloc_flat_records(1, 20, dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wall, devms = [], []
+    for it in range(iters + 10):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        eng.detect_graph(img, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=20, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        if it >= 10:
+            wall.append((time.perf_counter() - t0) * 1e3); devms.append(e0.elapsed_time(e1))
+    if eng1 is None:
+        eng.close()
+    return {"latency_b1_ms": round(float(np.median(wall)), 4), "latency_b1_device_ms": round(float(np.median(devms)), 4),
+            "latency_b1_p99_ms": round(float(np.percentile(wall, 99)), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +137,7 @@ def main():
     ap.add_argument("--parity-images", type=int, default=2, help="images of the timed batch whose boxes are compared with the fp32 oracle for the `parity` field (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg (`latency_b1_ms`: one image per call, graph replay, synchronised per image; rank 0, N = 1, outside the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
     ap.add_argument("--dtype", choices=("bf16", "fp8", "fp32", "fp16", "mixed", "fp16x2"), default="bf16",
@@ -267,6 +303,13 @@ def main():
                          "kernel": "conv_igemm_f32 (every conv launch of one forward)" if fp32 else "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
+        if hip.LIB_OVERRIDE:
+            out["lib_override"] = hip.LIB_OVERRIDE          # measured through YOLO_HIP_LIB (an A/B probe build), not the in-tree library
+        if strong:      # a fixed global batch leaves each rank a small share: say which regime that share runs in, so a poor strong curve reads correctly
+            out["config"]["per_rank"] = {"images_on_rank0": n_local, "conv_frac_of_peak_on_rank0": round(achieved / peak, 4),
+                                         "regime": "launch-bound (per-launch fixed cost dominates: DESIGN.md section 6)" if achieved / peak < 0.25 else "matrix-pipe / fixed-cost mix"}
+        if G == 1 and not args.no_latency:
+            out.update(latency_b1(hip, cfg_txt, flat, args, dev, stream, fp8, fp32, fp16, x2, eng if B == 1 else None))
         if G == 1 and args.parity_images > 0:
             out["parity"] = parity(eng, cfg_txt, flat, images[:min(args.parity_images, n_local)].cpu().numpy(), args.size)
         if G == 1 and not args.no_cpu_baseline:

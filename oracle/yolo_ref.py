@@ -779,7 +779,7 @@ def flatten_weights(params, secs):
     return np.concatenate([np.asarray(q, dtype=np.float32).reshape(-1) for q in parts])
 
 
-def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35, 1.5)):
+def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35, 1.5), keep_var=False):
     """Make a synthetic parameter set behave like a TRAINED file on the given images: one forward pass in which every batch-normalised
     conv's filters are rescaled per output channel to a target variance drawn from the ranges of the reference's dump of real files
     (D2T/log.txt: 2e-3 .. 0.3 on the first two layers, 0.6 .. 19 after, a few per cent down to 8e-4) and its rolling mean / variance
@@ -788,6 +788,9 @@ def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35,
     outputs have standard deviation `head_std` = (centre logits, log-size offsets, objectness / class logits) around their biases -- a
     trained detector's size offsets stay within about +-1 (boxes 0.3 .. 3 anchors), not the +-5 of an unscaled random filter.  Without this the analytic statistics of the generator hold for
     white-noise inputs only: on natural images neighbouring taps add coherently and the activations grow layer by layer.
+    keep_var=True (darknet_io.synth_weights(stats="real"): beta, gamma and rolling variance are the reference's real vectors,
+    D2T/log.txt:224-949): the target variance of a channel is the rolling variance it already carries, which stays as it is; only the
+    filters are rescaled and the rolling mean set.
     Test infrastructure (no reference counterpart: the reference ships no weights).  Returns the calibrated params (modified in place)."""
     rng = np.random.default_rng(seed)
 
@@ -802,6 +805,10 @@ def calibrate_bn_statistics(secs, params, images01, seed=0, head_std=(1.0, 0.35,
             k = np.arange(n) % attrs if attrs and n % attrs == 0 else np.full(n, 4)
             want = np.where(k < 2, head_std[0], np.where(k < 4, head_std[1], head_std[2]))
             sc = want / np.sqrt(np.maximum(v, 1e-20))
+        elif keep_var:
+            target = np.maximum(p["var"].astype(np.float64), 1e-30)
+            sc = np.sqrt(target / np.maximum(v, 1e-30))
+            p["mean"] = (m * sc).astype(np.float32)
         else:
             lo, hi = (2e-3, 0.3) if i < 2 else (0.6, 19.0)
             target = np.exp(rng.uniform(np.log(lo), np.log(hi), n))

@@ -130,10 +130,10 @@ def test_fp16_tuned_plan_and_boxes_416_b32(hiplib):
     ref = oracle_detections(txt, flat, img, 416)
     miou, mds, cnt, lost = box_deviation(ref, det, 1e-3)
     print("fp16 416 b32 vs fp32 oracle: %d candidates over 32 images, min IoU %.4f, max |dscore| %.5f, lost %d" % (cnt, miou, mds, lost))
-    assert cnt > 100 and lost == 0 and miou >= 0.998 and mds <= 1e-3
+    assert cnt > 100 and lost == 0 and miou >= 0.9985 and mds <= 1e-3        # measured 0.9990 / 0.00015: AT north_star's 0.999, no margin (DESIGN.md section 4 says so)
 
 
-@pytest.mark.parametrize("stats", ["benign", "log"])
+@pytest.mark.parametrize("stats", ["benign", "log", "real"])
 def test_fp16_reference_images(hiplib, stats):
     """The reference's six jpgs through the detector entry point in fp16 storage, against the fp32 oracle: benign statistics and
     trained-file statistics (where bf16 storage drops to IoU ~0.65, tests/test_gpu_natural.py)."""
@@ -146,7 +146,7 @@ def test_fp16_reference_images(hiplib, stats):
     miou, mds, cnt, lost = box_deviation(ref, det, 1e-2, thr=d.threshold)
     print("natural images, %s weights, fp16: %d candidates over 6 images, min IoU %.4f, max |dscore| %.5f, below threshold %d" % (stats, cnt, miou, mds, lost))
     d.engine.close()
-    if stats == "benign":
-        assert lost == 0 and miou >= 0.998 and mds <= 1e-3
-    else:
-        assert lost == 0 and miou >= 0.93 and mds <= 3e-2
+    # measured: benign 0.9988 / 0.0002 -- just UNDER north_star's 0.999, and said so there; log (drawn vectors) 0.9619 /
+    # 0.023; real (the reference's own vectors, round 5): see DESIGN.  Guards sit just under the measured values.
+    lo, hi = {"benign": (0.9985, 1e-3), "log": (0.95, 3e-2), "real": (0.99, 5e-3)}[stats]
+    assert lost == 0 and miou >= lo and mds <= hi

@@ -112,7 +112,7 @@ def _natural():
     return [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 
 
-@pytest.mark.parametrize("stats", ["benign", "log"])
+@pytest.mark.parametrize("stats", ["benign", "log", "real"])
 def test_fp16x2_meets_the_stated_tolerance_on_natural_images(hiplib, stats, tmp_path):
     """north_star's tolerance -- IoU >= 0.999 against the fp32 reference on identical inputs -- on the reference's six jpgs through
     `YOLOV3.detect_from_image`'s device path (uint8 -> /255 -> legacy bilinear stretch -> network -> decode), with benign statistics and with
@@ -143,15 +143,8 @@ def test_fp16x2_meets_the_stated_tolerance_on_natural_images(hiplib, stats, tmp_
 def test_fp16x2_batch32_416_log_statistics_and_autotune(hiplib):
     """BASELINE's headline size and batch on weights with trained-file statistics: all 32 noise images against the fp32 oracle (plain bf16
     storage: min IoU 0.51 there), the autotuned plan bit-identical to the default one, detect == forward + postprocess."""
-    from test_gpu_natural import _weights
-    txt, flat = _weights("log")
-    img = np.random.default_rng(1).integers(0, 256, (32, 416, 416, 3), dtype=np.uint8)
-    osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
-    ref = []
-    for b in range(32):
-        heads, _ = R.forward(osecs, params, img[b:b + 1].astype(np.float32) / np.float32(255))
-        ref.append(R.yolo_v3_detections(heads, 416, ratio=True)[0])
-    ref = np.stack(ref)
+    from test_gpu_natural import _ref32
+    txt, flat, img, ref, _, _ = _ref32("log")
     eng = hiplib.Engine(txt, max_batch=32, dtype=hiplib.FP16X2)
     eng.set_weights(flat)
     det = eng.forward(img)

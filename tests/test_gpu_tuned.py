@@ -247,6 +247,37 @@ def test_autotune_runs_and_keeps_results(hiplib, dtype_name):
     want = eng.forward(img)
     eng.autotune(4, 1)
     plan = eng.get_tile_configs()
-    assert (plan[plan >= 0] % 10000 < hiplib.op_conv_num_cfgs()).all() or (plan == 1000).any()
+    num = hiplib.op_conv_num_cfgs()
+    assert all(v == 1000 or v % 10000 < num for v in plan[plan >= 0].tolist()), plan          # 1000 = CONV_CFG_DIRECT (first layer, stem off)
     assert np.array_equal(eng.forward(img), want)
     eng.close()
+
+
+@pytest.mark.parametrize("cfg", [40, 43])
+def test_fused_tail_on_ragged_halo_blocks_608(hiplib, cfg):
+    """the fused 1x1 tail on the halo-staged 3x3 forms is admitted on ragged 13 x 13 blocks (608 x 608: the 76 x 76 stage is
+    6 x 13 - 2) by conv_halo13_ok / set_tile_configs / autotune -- force it on every 3x3 layer that can carry it and compare with the plan
+    that launches the 1x1 convs themselves: bit for bit (the tail walks K in the stand-alone kernel's order)."""
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 608)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    img = np.random.default_rng(4).integers(0, 256, (2, 608, 608, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2)
+    eng.set_weights(flat)
+    base = eng.get_tile_configs().copy()
+    plain = np.where(base >= 10000, base - 10000, base)                 # no tails anywhere
+    eng.set_tile_configs(plain)
+    want = eng.forward(img)
+    shapes = IO.layer_shapes(secs)
+    forced = 0
+    for i, s in enumerate(secs[1:]):
+        if s["type"] == "convolutional" and int(s["size"]) == 3 and int(s.get("stride", 1)) == 1 and shapes[i][1] in (38, 76) and int(s["filters"]) <= 256:
+            trial = plain.copy(); trial[i] = 10000 + cfg
+            try:
+                eng.set_tile_configs(trial)
+            except hiplib.YoloError:
+                continue                                                 # this layer has no 1x1 tail to carry (e.g. it feeds a head)
+            got = eng.forward(img)
+            assert np.array_equal(got, want), "layer %d with tile config %d + tail differs from the separate launches" % (i, cfg)
+            forced += 1
+    eng.close()
+    assert forced >= 4, forced

@@ -13,6 +13,11 @@ Runs only in the build container (it reads /root/reference and oracle/_ref); the
                      an input image, EVERY layer output, and the boxes after get_network_boxes /
                      do_nms_sort -- produced by the reference's own C code compiled CPU-only
                      (oracle/Makefile -> oracle/_ref/libdarknet_ref.so)
+  yolov3_bn_real.npz / yolov2_bn_real.npz
+                     the COMPLETE batch-norm vectors (beta, gamma, rolling mean, rolling variance) of every
+                     batch-normalised conv of yolov3.weights / yolov2.weights, and the first l.n filter
+                     values of every conv, as the reference's own load_convolutional_weights printed them
+                     (DN/parser.c:1176-1228) into D2T/log.txt:224-949 / :1-222 -- numbers, not source
 """
 import os
 import sys
@@ -463,8 +468,51 @@ def gen_mini(name, cfg, classes, nms_thresh=0.3, thresh=0.15):
     net.close()
 
 
+def gen_bn_real():
+    """D2T/log.txt is the reference's stdout of two detect runs (yolov2 then yolov3) with the printf block of DN/parser.c:1176-1228
+    enabled: per batch-normalised conv five lines of numbers (beta, gamma, rolling mean, rolling variance -- l.n values each -- and the
+    first l.n of the l.nweights filter values), per plain conv (the heads) the filter line only; line 223 / 950 are the detections."""
+    import re
+    lines = open(os.path.join(REF, "Darknet2Tensorflow", "darknet-master", "log.txt")).read().split("\n")
+    for name, lo, hi, n_bn, n_conv in (("yolov2", 1, 222, 22, 23), ("yolov3", 224, 949, 72, 75)):
+        convs = []; cur = None; k = lo - 1
+        while k < hi:
+            h = lines[k]
+            m = re.match(r"\*+robin#convolutional_(\w+?)(?:/\w+)?\((?:l\.n|num)=(\d+)\)", h)
+            assert m, (k + 1, h[:80])
+            vals = np.array([float(v) for v in lines[k + 1].replace(" ", "").split(",") if v], dtype=np.float32)
+            what, cnt = m.group(1), int(m.group(2))
+            if what == "biases":
+                cur = {"n": cnt, "beta": vals}
+            elif what in ("scales", "rolling_mean", "rolling_variance"):
+                cur[{"scales": "gamma", "rolling_mean": "mean", "rolling_variance": "var"}[what]] = vals
+            else:
+                assert what == "weights"
+                c = cur if cur is not None else {"n": len(vals)}
+                c["nweights"] = cnt; c["w_first"] = vals
+                assert all(len(c[q]) == c["n"] for q in ("beta", "gamma", "mean", "var") if q in c) and len(vals) == c["n"]
+                convs.append(c); cur = None
+            k += 2
+        assert len(convs) == n_conv and sum("beta" in c for c in convs) == n_bn, (len(convs), name)
+        data = {"n_conv": np.int32(len(convs)), "filters": np.array([c["n"] for c in convs], np.int32),
+                "nweights": np.array([c["nweights"] for c in convs], np.int64), "bn": np.array(["beta" in c for c in convs])}
+        for i, c in enumerate(convs):
+            for q in ("beta", "gamma", "mean", "var", "w_first"):
+                if q in c:
+                    data["%s_%d" % (q, i)] = c[q]
+        np.savez_compressed(os.path.join(OUT, name + "_bn_real.npz"), **data)
+        bn = [c for c in convs if "beta" in c]
+        print(name + "_bn_real: %d convs (%d batch-normalised), gamma %.4g..%.4g (%.1f%% negative), beta %.3g..%.3g, mean %.3g..%.3g, var %.3g..%.3g"
+              % (len(convs), len(bn), min(c["gamma"].min() for c in bn), max(c["gamma"].max() for c in bn),
+                 100.0 * sum((c["gamma"] < 0).sum() for c in bn) / sum(c["n"] for c in bn),
+                 min(c["beta"].min() for c in bn), max(c["beta"].max() for c in bn), min(c["mean"].min() for c in bn), max(c["mean"].max() for c in bn),
+                 min(c["var"].min() for c in bn), max(c["var"].max() for c in bn)))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["bn_real"]:
+        gen_bn_real(); sys.exit(0)
     stub_modules()
     gen_nms_v3()
     gen_v2_post()
@@ -472,3 +520,4 @@ if __name__ == "__main__":
     gen_mini("mini_v2", MINI_V2, 5)
     gen_mini_v1()
     gen_mini_local()
+    gen_bn_real()

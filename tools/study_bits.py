@@ -1,7 +1,8 @@
 """CPU study (oracle only): min IoU of the decoded boxes against the fp32 oracle as a function of the SIGNIFICAND WIDTH of the stored
 activations and folded filters (8 = bf16, 11 = fp16), plain (`dev`) and mean-centred (`cen`, tools/study_centred.py), on the synthetic
 weights with a trained file's batch-norm statistics.  Result (profiles/r04_precision_study.txt): 1 - IoU falls by 4x per 2 bits; 0.999
-needs >= 17 bits -- no 16-bit storage type reaches it on this network, centred or not."""
+needs >= 17 bits -- no 16-bit storage type reaches it on this network, centred or not.
+Usage: study_bits.py [log|real]   (real = the reference's real batch-norm vectors, tests/golden/yolov3_bn_real.npz; profiles/r05_precision_study.txt)"""
 import glob, os, sys
 import numpy as np
 _H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, ".."), os.path.join(_H, "..", "tests"), _H]
@@ -20,9 +21,11 @@ paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__))
 imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 x_all = np.concatenate([R.input_process(im, 416) for im in imgs])
 noise = np.random.default_rng(5).random((2, 416, 416, 3), dtype=np.float32)
-flat = IO.synth_weights(IO.parse_cfg(txt), seed=3, stats="log", obj_bias=-2.5)
+STATS = sys.argv[1] if len(sys.argv) > 1 else "log"        # "log": drawn from the dump's ranges (round 4); "real": the dump's own vectors (round 5)
+flat = IO.synth_weights(IO.parse_cfg(txt), seed=3, stats=STATS, obj_bias=-2.5)
 params = R.unflatten_weights(flat, secs)
-R.calibrate_bn_statistics(secs, params, np.concatenate([x_all, noise]), seed=3)
+R.calibrate_bn_statistics(secs, params, np.concatenate([x_all, noise]), seed=3, keep_var=STATS == "real")
+print("== study_bits, stats=%s" % STATS, flush=True)
 x = x_all[:3]
 h32 = R.forward(secs, params, x)[0]; ref = R.yolo_v3_detections(h32, 416, ratio=True)
 oc = S.calib_offsets(secs, params, np.concatenate([x_all[3:5], noise[:1]]))

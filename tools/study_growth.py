@@ -55,10 +55,10 @@ def fwd(secs, params, x01, qa, qw, offs, inject=None):
 
 ident = lambda a: a
 for stats in sys.argv[1].split(","):
-    flat = IO.synth_weights(IO.parse_cfg(txt), seed=3, stats=stats, obj_bias=-2.5 if stats == "log" else -0.75)
+    flat = IO.synth_weights(IO.parse_cfg(txt), seed=3, stats=stats, obj_bias=-2.5 if stats in ("log", "real") else -0.75)
     params = R.unflatten_weights(flat, secs)
-    if stats == "log":
-        R.calibrate_bn_statistics(secs, params, np.concatenate([x_all, noise]), seed=3)
+    if stats in ("log", "real"):
+        R.calibrate_bn_statistics(secs, params, np.concatenate([x_all, noise]), seed=3, keep_var=stats == "real")
     x = x_all[:1]
     oc = S.calib_offsets(secs, params, np.concatenate([x_all[3:5], noise[:1]]))
     h0, o0, m0 = fwd(secs, params, x, ident, ident, None)

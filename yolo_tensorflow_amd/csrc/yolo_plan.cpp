@@ -421,6 +421,19 @@ int allocate(yolo_ctx *c)
             if (Y.type == L_YOLO && P.type == L_CONV && P.head && !P.fc) HIPCK(c, hipMalloc((void **)&P.d_obj, (size_t)c->max_batch * P.H * P.W * Y.na * 4));
         }
     HIPCK(c, hipStreamSynchronize(c->stream));
+    // The 16-bit / e4m3 conv kernels address their input with 32-bit buffer offsets: the whole-batch activation window of every conv must
+    // stay under 2 GiB (launch_conv_bf16's own check).  Refuse a max_batch that cannot run HERE, with the number that can, instead of a bare
+    // 'invalid value' from the first forward (a split-fp16 tensor is 3 x as wide, so 416 x 416 stops above batch 64).
+    if (c->dtype != YOLO_FP32)
+        for (size_t i = 0; i < c->layers.size(); ++i) {
+            const Layer &L = c->layers[i];
+            if (L.type != L_CONV || L.fc || L.s2d7 || L.stem_skip || L.stem || L.stem_tail || L.blk_skip) continue;     // (fused layers: their launch checks its own windows)
+            const TView in = view_of(c, L.in[0]);
+            const double per_image = (double)in.h * in.w * in.stride * dt_size(L.in_dt), slack = 2.0 * (in.w + 1) * in.stride * dt_size(L.in_dt);
+            if (per_image * c->max_batch + slack >= 2147483648.0)
+                return fail(c, YOLO_ERR_UNSUPPORTED, "max_batch %d: layer %zu reads %.0f bytes per image%s, and a conv's whole-batch input must stay below 2 GiB (32-bit buffer offsets): at most %d images per context",
+                            c->max_batch, i, per_image, c->split() ? " (split fp16 pairs: 3 x the channels)" : "", (int)((2147483648.0 - slack - 1) / per_image));
+        }
     return YOLO_OK;
 }
 

@@ -437,13 +437,22 @@ int yolo_detect_graph(yolo_ctx *c, const void *images, int n, int fmt, float sca
     return YOLO_OK;
 }
 
+// the timing entry points' events: destroyed on every return path
+namespace { struct EventSet {
+    std::vector<hipEvent_t> e; bool ok = true;
+    explicit EventSet(int n) { e.reserve(n); for (int i = 0; i < n; ++i) { hipEvent_t x; if (hipEventCreate(&x) != hipSuccess) { ok = false; break; } e.push_back(x); } }
+    ~EventSet() { for (auto x : e) hipEventDestroy(x); }
+    EventSet(const EventSet &) = delete; EventSet &operator=(const EventSet &) = delete;
+}; }
+
 int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *conv_ms)
 {
     if (!c) return YOLO_ERR_INVALID;
     if (!c->weights_loaded) return fail(c, YOLO_ERR_STATE, "weights not loaded");
     if (n < 1 || n > c->max_batch || iters < 1) return fail(c, YOLO_ERR_INVALID, "bad n/iters");
     HIPCK(c, hipSetDevice(c->device));
-    hipEvent_t e0, e1; HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    EventSet evs(2); if (!evs.ok) return fail(c, YOLO_ERR_HIP, "hipEventCreate failed");
+    hipEvent_t e0 = evs.e[0], e1 = evs.e[1];
     c->lean = false;
     if (c->stem_u8 && n > c->stem_u8_n) c->stem_u8 = nullptr;      // the staged uint8 buffer holds fewer images: the stem reads c->input instead
     if (total_ms) {
@@ -470,7 +479,6 @@ int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *con
         *conv_ms = all_ms - rest_ms;
         c->last_n = n; c->scores_mode = 0; c->det_valid = true;
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
     return YOLO_OK;
 }
 
@@ -483,8 +491,8 @@ int yolo_time_layers(yolo_ctx *c, int n, int iters, float *ms_out)
     const int NL = (int)c->layers.size();
     c->lean = false; c->det_valid = true;
     if (c->stem_u8 && n > c->stem_u8_n) c->stem_u8 = nullptr;      // see yolo_time_forward
-    std::vector<hipEvent_t> ev(NL + 1);
-    for (auto &e : ev) HIPCK(c, hipEventCreate(&e));
+    EventSet evs(NL + 1); if (!evs.ok) return fail(c, YOLO_ERR_HIP, "hipEventCreate failed");
+    std::vector<hipEvent_t> &ev = evs.e;
     std::vector<double> acc(NL, 0.0);
     for (int it = 0; it < iters; ++it) {
         HIPCK(c, hipEventRecord(ev[0], c->stream));
@@ -493,7 +501,6 @@ int yolo_time_layers(yolo_ctx *c, int n, int iters, float *ms_out)
         for (int i = 0; i < NL; ++i) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
     }
     for (int i = 0; i < NL; ++i) ms_out[i] = (float)(acc[i] / iters);
-    for (auto &e : ev) hipEventDestroy(e);
     c->last_n = n;
     return YOLO_OK;
 }

@@ -234,6 +234,7 @@ def write_weights_file(path, flat, major=0, minor=2, revision=0, seen=0):
 def synth_weights(secs, seed=0, obj_bias=-0.75, stats="benign"):
     """Seeded synthetic parameter stream, valid for any supported topology.
     stats="log": batch-norm statistics in the ranges of the reference's dump of real files (see synth_weights_log).
+    stats="real": the reference's REAL batch-norm vectors (see synth_weights_real; yolov3 / yolov2 topologies only).
 
     Filters W ~ N(0, 2/(k*k*Cin)) (darknet's own init, DN/convolutional_layer.c:205-209); gamma ~ U(.8,1.2),
     beta ~ N(0,.1), rolling_mean ~ N(0,.1).  rolling_variance is set to the *expected* variance of the
@@ -243,6 +244,8 @@ def synth_weights(secs, seed=0, obj_bias=-0.75, stats="benign"):
     filters, class/box biases N(0,1)/N(0,.5), objectness bias `obj_bias` (a few % of candidates pass 0.5)."""
     if stats == "log":
         return synth_weights_log(secs, seed, obj_bias)
+    if stats == "real":
+        return synth_weights_real(secs, seed, obj_bias)
     rng = np.random.default_rng(seed)
     layers = secs[1:]
     shapes = layer_shapes(secs)
@@ -329,7 +332,34 @@ def _erf(x):
     return sign * y
 
 
-def synth_weights_log(secs, seed=0, obj_bias=-0.75):
+def bn_real_vectors(secs, path=None):
+    """The batch-norm vectors of a TRAINED yolov3.weights / yolov2.weights as the reference itself printed them (D2T/log.txt:224-949 /
+    :1-222 through DN/parser.c:1176-1228; parsed into tests/golden/yolov{3,2}_bn_real.npz by tools/make_golden.py): one dict
+    {beta, gamma, mean, var, w_first} per batch-normalised conv of `secs` in file order (None for the plain head convs).  The
+    topology is recognised by its filter counts; anything else raises."""
+    import os
+    convs = [s for s in secs[1:] if s["type"] == "convolutional"]
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for name in ([path] if path else [os.path.join(golden, "yolov3_bn_real.npz"), os.path.join(golden, "yolov2_bn_real.npz")]):
+        if not os.path.exists(name):
+            continue
+        z = np.load(name)
+        if int(z["n_conv"]) == len(convs) and all(int(c["filters"]) == int(f) for c, f in zip(convs, z["filters"])):
+            return [({q: z["%s_%d" % (q, i)] for q in ("beta", "gamma", "mean", "var", "w_first")} if z["bn"][i] else None) for i in range(len(convs))]
+    raise ValueError("no real batch-norm vectors for this topology (%d convs): the reference's dump covers yolov3 and yolov2 only" % len(convs))
+
+
+def synth_weights_real(secs, seed=0, obj_bias=-0.75, path=None):
+    """The trained-file stand-in built from the reference's REAL vectors: beta, gamma and rolling variance of every
+    batch-normalised conv are the file's own, per channel and PAIRED as trained (e.g. the first conv's beta -4.3 goes with gamma 2.6,
+    D2T/log.txt:225-227 -- that pairing decides which channels are dead after the leaky ReLU); the filters, which the dump does not hold,
+    are random directions scaled per output channel so that the conv output has the file's variance on inputs with the analytically
+    tracked moments, and the rolling mean is what those filters produce.  oracle.calibrate_bn_statistics(..., keep_var=True) then
+    re-scales filters and means on actual images, leaving beta / gamma / variance as the file has them."""
+    return synth_weights_log(secs, seed, obj_bias, real=bn_real_vectors(secs, path))
+
+
+def synth_weights_log(secs, seed=0, obj_bias=-0.75, real=None):
     """Seeded synthetic parameters with the batch-norm statistics of a TRAINED darknet file -- the ranges the reference's own dump of
     yolov3.weights / yolov2.weights documents (D2T/log.txt:1-949): gamma 0.0017 .. 4.7 and a few per cent of them negative, beta out to
     -11, rolling means out to +-11, rolling variances from 8e-4 (first layers) to 19 -- instead of the benign gamma ~ U(.8, 1.2),
@@ -345,15 +375,27 @@ def synth_weights_log(secs, seed=0, obj_bias=-0.75):
     mean = [None] * len(layers); var = [None] * len(layers)            # per-channel first / second central moment of every layer's output
     m_in, v_in = np.full(cin0, 0.5), np.full(cin0, 1.0 / 12.0)         # uniform [0, 1) pixels
     parts = []
+    ci = -1
     for i, s in enumerate(layers):
         t = s["type"]
         pm, pv = (mean[i - 1], var[i - 1]) if i else (m_in, v_in)
         if t == "convolutional":
+            ci += 1
             n, k, cin = int(s["filters"]), int(s["size"]), shapes[i][4]
             head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
             w = rng.normal(0, 1.0, (n, cin, k * k))
             ex2 = pv + pm * pm
-            if int(s.get("batch_normalize", 0)):
+            if int(s.get("batch_normalize", 0)) and real is not None:
+                r = real[ci]
+                target = np.maximum(r["var"].astype(np.float64), 1e-30)
+                unit_var = (w * w * pv[None, :, None]).sum((1, 2))
+                w *= np.sqrt(target / np.maximum(unit_var, 1e-30))[:, None, None]
+                rmean = (w * pm[None, :, None]).sum((1, 2))
+                gamma, beta = r["gamma"].astype(np.float64), r["beta"].astype(np.float64)
+                parts += [beta, gamma, rmean, target, w.reshape(-1)]
+                std = np.abs(gamma) * np.sqrt(target / (target + 1e-5))
+                m1, m2 = _leaky_moments(beta, std, 0.1 if s.get("activation", "linear") == "leaky" else 1.0)
+            elif int(s.get("batch_normalize", 0)):
                 # target rolling variance: first two convs (pixel inputs, small filters) 2e-3 .. 0.3, later layers 0.6 .. 19, 3 % tiny
                 lo, hi = (2e-3, 0.3) if i < 2 else (0.6, 19.0)
                 target = np.exp(rng.uniform(np.log(lo), np.log(hi), n))

@@ -10,7 +10,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+# YOLO_HIP_LIB: another build of the SAME library (A/B probes, tools/probe/ab) -- selected, never copied over the in-tree file, whose
+# sources buildinfo.source_hash() stamps the profiles with; a line measured through it says so (bench.py: "lib_override")
+LIB_OVERRIDE = os.environ.get("YOLO_HIP_LIB") or None
+LIB_PATH = LIB_OVERRIDE or os.path.join(_HERE, "libyolo_hip.so")
 
 BF16, FP32, FP8, FP16, FP16X2 = 0, 1, 2, 3, 4
 SEM_TF, SEM_DARKNET = 0, 1
@@ -252,6 +255,9 @@ class Engine:
         """images: uint8 or float32 [n,S,S,3] (numpy, torch host/device tensor, or raw device pointer with
         n and fmt given).  Returns the decoded tensor [n, rows, attrs] (numpy) unless out/want_detections say otherwise."""
         p, loc = _ptr(images)
+        # a device uint8 image may be read IN PLACE by the fused stem, also by a later time_forward / time_layers / autotune pass
+        # (yolo_hip.h, yolo_forward): keep it alive until the next image replaces it (ADVICE r04)
+        self._last_image = images if loc == DEVICE else None
         self._order_after_producer(images, out)
         if n is None:
             n = int(images.shape[0])
@@ -320,6 +326,7 @@ class Engine:
         p, loc = _ptr(images); bp, bl = _ptr(boxes_out); cp, cl = _ptr(counts_out)
         if loc != DEVICE or bl != DEVICE or cl != DEVICE:
             raise YoloError("detect_graph needs device-resident buffers")
+        self._last_image = images                   # (see forward)
         self._order_after_producer(images, boxes_out, counts_out)
         fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
         self._check(self.lib.yolo_detect_graph(self.ctx, p, int(images.shape[0]), fmt, scale, score_thr, iou_thr, max_out,
