@@ -53,8 +53,13 @@ enum yolo_dtype { YOLO_BF16 = 0, YOLO_FP32 = 1, YOLO_FP8 = 2,
                                      * lo = f16(v - hi) -- 22 significant bits -- and a conv forms W_hi x_hi + W_hi x_lo + W_lo x_hi on the
                                      * fp16 MFMA with fp32 accumulation (three products per algorithmic one, W_lo x_lo is dropped).  The
                                      * configuration that meets north_star's IoU >= 0.999 on weights with a trained file's statistics at
-                                     * several times the exact-fp32 path's rate; no fusions (every layer is its own launch), [connected] /
-                                     * [local] layers are not served.  DESIGN.md section 3.6 */
+                                     * several times the exact-fp32 path's rate; shortcuts are folded into the conv epilogues, the stem /
+                                     * residual-block / 1x1-tail fusions are off on tensors stored as pairs; [connected] / [local] layers are
+                                     * not served.  Mixed plans (round 5): `yolo_pair=0` on a [convolutional] section stores that layer's
+                                     * output -- and what is derived from it without arithmetic -- as PLAIN fp16 (`yolo_pair_input=0` in
+                                     * [net]: the image); a conv that reads a plain tensor runs one MFMA product per algorithmic one, and
+                                     * stretches of plain tensors are served by the fp16 configuration's fused kernels.  Both operands of
+                                     * a shortcut and all inputs of a concatenation share one form.  DESIGN.md section 3.6 */
 enum yolo_semantics { YOLO_SEM_TF = 0, YOLO_SEM_DARKNET = 1 };
 /* TF: bilinear `_upsample` (V3/yolo_v3.py:162-192) + tf.space_to_depth (V2/model_darknet19_slim.py:44);
  * DARKNET: nearest upsample (DN/blas.c:334) + reorg_cpu (DN/blas.c:9) -- lets the whole network be

@@ -947,15 +947,25 @@ def split_f16(x):
     return hi, to_f16(x - hi)
 
 
-def forward_f16x2(secs, params, x, semantics="tf", collect=None):
+def forward_f16x2(secs, params, x, semantics="tf", collect=None, pair=None):
     """Emulation of the device's split-fp16 configuration: every stored activation and folded filter is a pair (hi, lo) of fp16 numbers;
     a conv is W_hi x_hi + W_hi x_lo + W_lo x_hi (+ fp32 bias) in fp32 -- W_lo x_lo is dropped, as on the device --, the shortcut and the
     layers that move or interpolate values work on hi + lo and split again; head convs stay fp32.  `x` is [N,S,S,3] float32 in 0..1.
+    `pair` (round 5, mixed plans: darknet_io.pair_closure): {layer index: bool, -1 = the image}; a tensor whose entry is False is PLAIN fp16
+    (hi only, lo = 0), a conv that reads a plain tensor multiplies it by fp16-rounded filters (one product), a shortcut of plain operands
+    adds and rounds once; None = pairs everywhere.
     Returns (heads, outs) like forward(); outs[i] is the JOINED value hi + lo of layer i's tensor.  Test infrastructure."""
     layers = secs[1:]
     outs, heads = [], []
     ci = 0
-    xs = split_f16(np.asarray(x, dtype=np.float32))
+    is_pair = (lambda i: True) if pair is None else (lambda i: bool(pair.get(i, True)))
+    def store(v, i):
+        v = np.asarray(v, dtype=np.float32)
+        if is_pair(i):
+            return split_f16(v)
+        h = to_f16(v)
+        return h, np.zeros_like(h)
+    xs = store(x, -1)
     for i, s in enumerate(layers):
         t = s["type"]
         if t == "convolutional":
@@ -964,31 +974,34 @@ def forward_f16x2(secs, params, x, semantics="tf", collect=None):
             is_head = i + 1 < len(layers) and layers[i + 1]["type"] in ("yolo", "region")
             w, b = fold_bn(p, mode="darknet" if semantics == "darknet" else "tf")
             wh, wl = split_f16(w); xh, xl = xs
-            y = (conv2d_nhwc(xh, wh, st) + conv2d_nhwc(xl, wh, st) + conv2d_nhwc(xh, wl, st) + b).astype(np.float32)
+            if is_pair(i - 1):
+                y = (conv2d_nhwc(xh, wh, st) + conv2d_nhwc(xl, wh, st) + conv2d_nhwc(xh, wl, st) + b).astype(np.float32)
+            else:
+                y = (conv2d_nhwc(xh, wh, st) + b).astype(np.float32)
             act = s.get("activation", "logistic")
             if act == "leaky":
                 y = leaky_relu(y)
             elif act != "linear":
                 raise ValueError(act)
             y = y.astype(np.float32)
-            xs = (y, np.zeros_like(y)) if is_head else split_f16(y)
+            xs = (y, np.zeros_like(y)) if is_head else store(y, i)
         elif t == "shortcut":
             f = int(s["from"]); f = f if f >= 0 else i + f
             a, b2 = outs[i - 1], outs[f]
-            xs = split_f16((a[0] + a[1]) + (b2[0] + b2[1]))
+            xs = store((a[0] + a[1]) + (b2[0] + b2[1]), i)
         elif t == "route":
             ls = [int(v) for v in s["layers"].split(",")]
             ls = [l if l >= 0 else i + l for l in ls]
             xs = tuple(np.concatenate([outs[l][k] for l in ls], axis=-1) for k in (0, 1)) if len(ls) > 1 else outs[ls[0]]
         elif t == "upsample":
             v = xs[0] + xs[1]
-            xs = split_f16(upsample_tf(v) if semantics == "tf" else upsample_nearest(v, int(s.get("stride", 2))))
+            xs = store(upsample_tf(v) if semantics == "tf" else upsample_nearest(v, int(s.get("stride", 2))), i)
         elif t == "maxpool":
             st = int(s.get("stride", 1)); k = int(s.get("size", st))
-            xs = split_f16(max_pool(xs[0] + xs[1], k, st, int(s.get("padding", (k - 1) // 2))))
+            xs = store(max_pool(xs[0] + xs[1], k, st, int(s.get("padding", (k - 1) // 2))), i)
         elif t == "reorg":
             st = int(s.get("stride", 1)); v = xs[0] + xs[1]
-            xs = split_f16(space_to_depth(v, st) if semantics == "tf" else reorg_darknet(v, st))
+            xs = store(space_to_depth(v, st) if semantics == "tf" else reorg_darknet(v, st), i)
         elif t in ("yolo", "region"):
             heads.append((s, outs[i - 1][0]))
             outs.append(None)

@@ -147,6 +147,12 @@ def test_fp16_reference_images(hiplib, stats):
     print("natural images, %s weights, fp16: %d candidates over 6 images, min IoU %.4f, max |dscore| %.5f, below threshold %d" % (stats, cnt, miou, mds, lost))
     d.engine.close()
     # measured: benign 0.9988 / 0.0002 -- just UNDER north_star's 0.999, and said so there; log (drawn vectors) 0.9619 /
-    # 0.023; real (the reference's own vectors, round 5): see DESIGN.  Guards sit just under the measured values.
-    lo, hi = {"benign": (0.9985, 1e-3), "log": (0.95, 3e-2), "real": (0.99, 5e-3)}[stats]
+    # 0.023; real (the reference's own vectors, round 5): the five ordinary jpgs and person.jpg apart (test_gpu_natural.real_split).
+    # Guards sit just under the measured values.
+    if stats == "real":
+        (miou, mds, cnt, lost), hard = N.real_split(ref, det, 1e-2, d.threshold)
+        print("   ... the five ordinary jpgs: %d candidates, min IoU %.4f, max |dscore| %.5f, lost %d;  person.jpg: %d candidates, min IoU %.4f, max |dscore| %.4f, lost %d"
+              % (cnt, miou, mds, lost, hard[2], hard[0], hard[1], hard[3]))
+        assert hard[0] >= 0.30 and hard[1] <= 0.12 and hard[3] <= 12        # measured 0.336 / 0.093 / 7 (the oracle's fp16 emulation: 0.42 / 0.147 / 9)
+    lo, hi = {"benign": (0.9985, 1e-3), "log": (0.95, 3e-2), "real": (0.994, 2e-3)}[stats]        # (real, the five ordinary jpgs: measured 0.9955 / 0.0007)
     assert lost == 0 and miou >= lo and mds <= hi

@@ -527,3 +527,26 @@ def test_fused_residual_block_equals_the_two_layers(hiplib, monkeypatch, dtype_n
     g = size // 4
     assert plain_bytes - fused_bytes == 2 * 2 * batch * g * g * 64 * 2
     assert np.isfinite(got).all() and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype_name,size,batch", [("bf16", 416, 3), ("fp16", 416, 1), ("bf16", 608, 2), ("bf16", 320, 1)])
+def test_fused_first_residual_block_equals_the_separate_launches(hiplib, monkeypatch, dtype_name, size, batch):
+    """conv_block64.hip (round 5: darknet-53's FIRST residual block -- 1x1 64 -> 32, 3x3 32 -> 64 and the shortcut, cfg layers 2-4 -- in one
+    launch, two workgroups per CU, the shortcut taken from the x tile in LDS; opt-in, YOLO_RESBLOCK64=1: measured slower than what it
+    replaces) against the default plan, where layer 2 is the stem's 1x1 tail and layer 3 the halo-staged 32 -> 64 conv: decoded tensors bit
+    for bit (same roundings, same K order).  208 x 208 is whole 13 x 13 blocks; 304 x 304 (608) and 160 x 160 (320) have ragged ones on the
+    bottom / right edge."""
+    dtype = {"bf16": hiplib.BF16, "fp16": hiplib.FP16}[dtype_name]
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=23)
+    img = np.random.default_rng(24).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    ref = hiplib.Engine(txt, max_batch=batch, dtype=dtype)
+    ref.set_weights(flat); want = ref.forward(img); plain_bytes = ref.conv_bytes(batch); ref.close()
+    monkeypatch.setenv("YOLO_RESBLOCK64", "1")
+    eng = hiplib.Engine(txt, max_batch=batch, dtype=dtype)
+    eng.set_weights(flat); got = eng.forward(img); fused_bytes = eng.conv_bytes(batch)
+    # a batch-1 pass of image 0 through the same context: another block count per workgroup, same result
+    alone = eng.forward(img[:1]); eng.close()
+    assert np.isfinite(got).all() and np.array_equal(got, want)
+    assert fused_bytes == plain_bytes        # (the counted tensors are the same size either way: what the block saves is the shortcut's re-read of x, which conv_bytes never counted)
+    assert np.array_equal(alone[0], got[0])

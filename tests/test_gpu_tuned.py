@@ -253,11 +253,11 @@ def test_autotune_runs_and_keeps_results(hiplib, dtype_name):
     eng.close()
 
 
-@pytest.mark.parametrize("cfg", [40, 43])
-def test_fused_tail_on_ragged_halo_blocks_608(hiplib, cfg):
+def test_fused_tail_on_ragged_halo_blocks_608(hiplib):
     """the fused 1x1 tail on the halo-staged 3x3 forms is admitted on ragged 13 x 13 blocks (608 x 608: the 76 x 76 stage is
-    6 x 13 - 2) by conv_halo13_ok / set_tile_configs / autotune -- force it on every 3x3 layer that can carry it and compare with the plan
-    that launches the 1x1 convs themselves: bit for bit (the tail walks K in the stand-alone kernel's order)."""
+    6 x 13 - 2) by conv_halo13_ok / set_tile_configs / autotune -- force it, with every halo configuration that can carry a tail (the
+    176 x 256 ones: set_tile_configs refuses the others), on every 3x3 layer that has one to carry, and compare with the plan that launches
+    the 1x1 convs themselves: bit for bit (the tail walks K in the stand-alone kernel's order)."""
     txt = IO.with_input_size(IO.cfg_text("yolov3"), 608)
     secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
     img = np.random.default_rng(4).integers(0, 256, (2, 608, 608, 3), dtype=np.uint8)
@@ -268,16 +268,18 @@ def test_fused_tail_on_ragged_halo_blocks_608(hiplib, cfg):
     eng.set_tile_configs(plain)
     want = eng.forward(img)
     shapes = IO.layer_shapes(secs)
-    forced = 0
-    for i, s in enumerate(secs[1:]):
-        if s["type"] == "convolutional" and int(s["size"]) == 3 and int(s.get("stride", 1)) == 1 and shapes[i][1] in (38, 76) and int(s["filters"]) <= 256:
-            trial = plain.copy(); trial[i] = 10000 + cfg
-            try:
-                eng.set_tile_configs(trial)
-            except hiplib.YoloError:
-                continue                                                 # this layer has no 1x1 tail to carry (e.g. it feeds a head)
-            got = eng.forward(img)
-            assert np.array_equal(got, want), "layer %d with tile config %d + tail differs from the separate launches" % (i, cfg)
-            forced += 1
+    forced = {}
+    for cfg in range(36, 44):                                            # the halo-staged configurations (csrc/conv_halo13.hip)
+        for i, s in enumerate(secs[1:]):
+            if s["type"] == "convolutional" and int(s["size"]) == 3 and int(s.get("stride", 1)) == 1 and shapes[i][1] in (38, 76) and int(s["filters"]) <= 256:
+                trial = plain.copy(); trial[i] = 10000 + cfg
+                try:
+                    eng.set_tile_configs(trial)
+                except hiplib.YoloError:
+                    continue                                             # this configuration / layer cannot carry a tail
+                got = eng.forward(img)
+                assert np.array_equal(got, want), "layer %d with tile config %d + tail differs from the separate launches" % (i, cfg)
+                forced[cfg] = forced.get(cfg, 0) + 1
     eng.close()
-    assert forced >= 4, forced
+    print("fused tail on ragged blocks, layers per halo configuration:", forced)
+    assert sum(forced.values()) >= 4 and len(forced) >= 1, forced

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * CB_NW) void conv_resblock_c128(const BlockArgs
             cb_u32x4 o = *(const __attribute__((address_space(3))) cb_u32x4 *)(lout + (px < CB_OPIX ? px : 0) * CB_OPITCH + piece * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb_pk<H16>(cb_lo<H16>(o[e]) + cb_lo<H16>(r[e]), cb_hi<H16>(o[e]) + cb_hi<H16>(r[e]));
-            __builtin_amdgcn_raw_buffer_store_b128(o, ro, ok ? (pix * a.out_stride + piece * 8) * 2 : 0x80000000u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, ro, ok ? (pix * a.out_stride + piece * 8) * 2 : 0x80000000u, 0, OUT_STORE_AUX);
         }
     };
     if (nt > 0) fetch_x(blk_of(0), (cb_lds_char *)lx_);

@@ -809,9 +809,9 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     split8(v, H, L);
                 }
                 const unsigned off = offs[it];
-                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off, 0, 0);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
-                __builtin_amdgcn_raw_buffer_store_b128(L, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + oblk, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + 2u * oblk, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off, 0, OUT_STORE_AUX);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
+                __builtin_amdgcn_raw_buffer_store_b128(L, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + oblk, 0, OUT_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + 2u * oblk, 0, OUT_STORE_AUX);
             }
         });
         }
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int q = 0; q < 4; ++q)
                     pw[q] = f32x2_to_fp8<true>(v[4 * q + 2] * a.out_inv_scale, v[4 * q + 3] * a.out_inv_scale,
                                                f32x2_to_fp8<false>(v[4 * q] * a.out_inv_scale, v[4 * q + 1] * a.out_inv_scale, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pw[0], pw[1], pw[2], pw[3]}, rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pw[0], pw[1], pw[2], pw[3]}, rs_out, off, 0, OUT_STORE_AUX);
                 if (TAIL_OK && EB == 1) if (a.w2) *(uint4 *)(smem + BP * RS + row * (BC + 16) + cc * 16) = uint4{pw[0], pw[1], pw[2], pw[3]};
             }
             if constexpr (TAIL_OK && EB == 1) if (a.w2) {
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int it = 0; it < (BP * CPR2 + NT - 1) / NT; ++it) {
                     int row, cc;
                     const unsigned off = piece_off(tid + it * NT, CPR2, 0, (unsigned)a.out2_stride, row, cc);
-                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, OUT_STORE_AUX);
                 }
             }
         } else {
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         }
                         if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, OUT_STORE_AUX);
                 }
             };
             if (res) store_tile(std::true_type{}); else store_tile(std::false_type{});
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 for (int it = 0; it < (BP * CPR2 + NT - 1) / NT; ++it) {
                     int row, cc;
                     const unsigned off = piece_off(tid + it * NT, CPR2, 0, (unsigned)a.out2_stride * 2u, row, cc);
-                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t *)(st2 + row * RS2 + cc * 16), rs_out2, off, 0, OUT_STORE_AUX);
                 }
             }
         }

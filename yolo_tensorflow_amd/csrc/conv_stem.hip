@@ -387,10 +387,10 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                 // ---- the piece of the older / newer tiles that rides with this step ----
                 if (h == 0) { sd[0] = *(const u32x4_t *)(lr + (lane >> 3) * ST_OPITCH + (lane & 7) * 16); sd[1] = *(const u32x4_t *)(lr + ((lane + 64) >> 3) * ST_OPITCH + (lane & 7) * 16); }
                 if (h == 1) {
-                    __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(0), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(1), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(0), 0, OUT_STORE_AUX); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(1), 0, OUT_STORE_AUX);
                     sd[0] = *(const u32x4_t *)(lr + ((lane + 128) >> 3) * ST_OPITCH + (lane & 7) * 16); sd[1] = *(const u32x4_t *)(lr + ((lane + 192) >> 3) * ST_OPITCH + (lane & 7) * 16);
                 }
-                if (h == 2) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(2), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(3), 0, 0); }
+                if (h == 2) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro, piece_off(2), 0, OUT_STORE_AUX); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro, piece_off(3), 0, OUT_STORE_AUX); }
                 if (h == 3) tail_frags(0);
                 if (h == 4) {
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
                             *(uint2 *)(lr2 + (q * ST_TW + l15) * ST_O2PITCH + (k * 16 + lq * 4) * 2) = stem_epi<H16>(acc2[q][k], *(const f32x4 *)(lw2_ + ST_W2_BYTES + (k * 16 + lq * 4) * 4), slope2);
                 }
                 if (h == 8) { sd[0] = *(const u32x4_t *)(lr2 + (lane >> 2) * ST_O2PITCH + (lane & 3) * 16); sd[1] = *(const u32x4_t *)(lr2 + ((lane + 64) >> 2) * ST_O2PITCH + (lane & 3) * 16); }
-                if (h == 9) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro2, piece2_off(0), 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro2, piece2_off(1), 0, 0); }
+                if (h == 9) { __builtin_amdgcn_raw_buffer_store_b128(sd[0], ro2, piece2_off(0), 0, OUT_STORE_AUX); __builtin_amdgcn_raw_buffer_store_b128(sd[1], ro2, piece2_off(1), 0, OUT_STORE_AUX); }
                 if (h == 10) epilogue(0, 0);
                 if (h == 11) epilogue(0, 2);
                 if (h == 12) { if constexpr (U8) convert_round(0); }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
                 o = uint4{ov[0], ov[1], ov[2], ov[3]};
             }
             if (oy < a.H && ox < a.W)
-                *(uint4 *)((bf16_t *)a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8) = o;
+                out_store16((bf16_t *)a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8, o.x, o.y, o.z, o.w);
         }
         // the next tile writes `lo` / `lres` only after its own pre-store barrier / its fetch: `lres` is re-filled at the
         // start of the next tile, so every thread must be past the reads above first

@@ -1,7 +1,33 @@
 // Internal launcher interface between the host planner (yolo_api.cpp) and the gfx950 kernels.
 #pragma once
+// Cache policy of the conv kernels' OUTPUT stores (aux operand of buffer_store on gfx950: 0 plain write-back, 2 nt, 16 sc1, 17 sc0 sc1).
+// Round 5: sc1 -- write-through to memory as the epilogue runs, instead of leaving up to 32 MB of dirty lines for the end-of-kernel L2
+// write-back, which is serial with the next launch.  Same-box A/B, YOLOv3-416 batch 32 bf16 (tools/probe/ab/ab_multi.sh, four interleaved
+// rounds): conv stack 2.578 -> 2.505 ms per forward, 12.01 -> 12.38 k img/s with sc1 on the tiled / halo conv's stores alone; nt: no change.
+#ifndef OUT_STORE_AUX
+#define OUT_STORE_AUX 16
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// the same policy for a 16-byte store through a plain pointer (kernels that do not hold a buffer descriptor for their output)
+typedef unsigned out_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void out_store16(void *p, unsigned x, unsigned y, unsigned z, unsigned w)
+{
+    const out_u32x4 v = {x, y, z, w};
+#if !defined(__HIP_DEVICE_COMPILE__)
+    *(out_u32x4 *)p = v;                   // (host pass: never executed)
+#elif OUT_STORE_AUX == 16
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif OUT_STORE_AUX == 17
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif OUT_STORE_AUX == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif OUT_STORE_AUX == 18
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#else
+    *(out_u32x4 *)p = v;
+#endif
+}
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
 struct fp8_t { uint8_t b; };   // raw OCP e4m3 (e4m3fn) bits in HBM
@@ -146,6 +172,10 @@ struct BlockArgs {
 };
 bool conv_resblock_ok(const BlockArgs &a);
 hipError_t launch_conv_resblock(const BlockArgs &a, hipStream_t s);
+// the same block at C = 64, Cmid = 32 (darknet-53's first residual block, 208 x 208 at 416 x 416): conv_block64.hip, two workgroups per CU,
+// shortcut from the x tile in LDS
+bool conv_resblock64_ok(const BlockArgs &a);
+hipError_t launch_conv_resblock64(const BlockArgs &a, hipStream_t s);
 // exact-fp32 MFMA conv (config 2); same argument meaning, in/wt/res are float
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t s);
 

@@ -205,7 +205,7 @@ int yolo_layer_output(yolo_ctx *c, int index, int n, float *out, size_t out_floa
     }
     hipError_t e = hipSuccess;
     float *wide = nullptr;
-    if (c->split() && v.dt == DT_F16) {        // split pairs: join into a Cp-strided fp32 image first, then gather the C logical channels
+    if (L.pair && v.dt == DT_F16) {        // split pairs: join into a Cp-strided fp32 image first, then gather the C logical channels
         const int cp = v.stride / 3;
         e = hipMalloc((void **)&wide, (size_t)n * L.H * L.W * cp * 4);
         if (e == hipSuccess) e = launch_split_to_f32(v.ptr, cp, wide, cp, (size_t)n * L.H * L.W, c->stream);

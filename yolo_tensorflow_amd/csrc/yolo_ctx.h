@@ -33,6 +33,8 @@ struct Layer {
     void *d_wf = nullptr;                   // bf16 1x1 conv that can ride in its producer's epilogue: its filters in MFMA-fragment order (tail_fragments)
     int in_dt = DT_BF16;                 // operand type of this conv's MFMA (filters are stored in it)
     int store_dt = DT_BF16;              // element type of this layer's output tensor (mixed plans: an fp8 network with bf16 islands, cfg key yolo_store)
+    bool pair = false;                   // YOLO_FP16X2 networks: this layer's output tensor is split-fp16 PAIRS ([pixel][hi | lo | hi], 3 x the channels); false there:
+                                         // plain fp16 (mixed plans, cfg key yolo_pair=0 on a [convolutional] section; layers that move data inherit their operands' form)
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
@@ -111,6 +113,8 @@ struct yolo_ctx {
     std::vector<float> user_scale, eff_scale;
     // split fp16 storage (YOLO_FP16X2): a logical tensor of C channels is [pixel][3 * Cp] f16, Cp = roundup(C, 8): hi | lo | hi blocks
     bool split() const { return dtype == YOLO_FP16X2; }
+    bool in_pair = false;                 // ... the network input is stored as pairs ([net] yolo_pair_input, default 1 in a YOLO_FP16X2 network)
+    bool pair_of(int idx) const { return idx < 0 ? in_pair : layers[idx].pair; }      // is tensor `idx` (-1: the input) stored as pairs?
     float *d_f32a = nullptr, *d_f32b = nullptr; size_t f32_cap = 0;      // split mode: fp32 staging of one tensor (input conversion, upsample / pool / reorg run in fp32 between a join and a split)
     int act_dt() const { return dtype == YOLO_FP32 ? DT_F32 : dtype == YOLO_FP8 ? DT_FP8 : (dtype == YOLO_FP16 || dtype == YOLO_FP16X2) ? DT_F16 : DT_BF16; }
     bool half_like() const { return dtype == YOLO_BF16 || dtype == YOLO_FP16; }      // 16-bit storage: the same kernels, the same plan

@@ -60,9 +60,13 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     int H = c->in_h, W = c->in_w, C = c->in_c;
     auto dims = [&](int idx, int &h, int &w, int &ch) { if (idx < 0) { h = c->in_h; w = c->in_w; ch = c->in_c; } else { h = c->layers[idx].H; w = c->layers[idx].W; ch = c->layers[idx].C; } };
     c->rows = 0; c->attrs = 0; c->conv_flops = 0; c->weights_count = 0;
+    // split-fp16 networks: per-tensor storage form (mixed plans): pairs unless a [convolutional] section says yolo_pair=0
+    // ([net] yolo_pair_input for the image); layers that move data inherit, both operands of a shortcut / all inputs of a route must agree
+    c->in_pair = c->split() && opt_i(net, "yolo_pair_input", 1) != 0;
     for (int i = 0; i < NL; ++i) {
         const Section &s = secs[i + 1]; Layer &L = c->layers[i];
         L.in = {i - 1};
+        if (!c->split() && (s.kv.count("yolo_pair") || net.kv.count("yolo_pair_input"))) return fail(c, YOLO_ERR_UNSUPPORTED, "layer %d: yolo_pair is a key of split-fp16 networks (YOLO_FP16X2)", i);
         if (s.type == "convolutional") {
             L.type = L_CONV; L.filters = opt_i(s, "filters", 1); L.size = opt_i(s, "size", 1); L.stride = opt_i(s, "stride", 1);
             L.pad = opt_i(s, "pad", 0) ? L.size / 2 : opt_i(s, "padding", 0);
@@ -86,7 +90,8 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
                 }
             }
             L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
-            if (c->split()) L.cin_pad *= 3;                     // the conv kernel's view of a split tensor: 3 * Cp channels (hi | lo | hi)
+            if (c->pair_of(i - 1)) L.cin_pad *= 3;              // the conv kernel's view of a split tensor: 3 * Cp channels (hi | lo | hi)
+            L.pair = c->split() && opt_i(s, "yolo_pair", 1) != 0;
             L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
             if (L.s2d7) { L.cin_pad = 32; L.kpad = 16 * 32; }          // 4x4 taps x (2x2 positions x 8 padded channels)
             H = (H + 2 * L.pad - L.size) / L.stride + 1; W = (W + 2 * L.pad - L.size) / L.stride + 1; C = L.filters;
@@ -191,8 +196,13 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             int dt = -1;
             for (int j : L.in) { const int dj = j < 0 ? c->act_dt() : c->layers[j].store_dt; if (dt >= 0 && dj != dt && (L.type == L_ROUTE || L.type == L_SHORTCUT)) return fail(c, YOLO_ERR_INVALID, "layer %d: operands stored in different types (yolo_store): a %s needs one type", i, L.type == L_ROUTE ? "route" : "shortcut"); if (dt < 0) dt = dj; }
             L.store_dt = dt >= 0 ? dt : c->act_dt();
+            if (c->split() && !L.in.empty() && L.type != L_YOLO && L.type != L_REGION && L.type != L_DETECT) {
+                L.pair = c->pair_of(L.in[0]);
+                for (int j : L.in) if (c->pair_of(j) != L.pair) return fail(c, YOLO_ERR_INVALID, "layer %d: operands stored in different forms (yolo_pair): a %s needs pairs or plain fp16 throughout", i, L.type == L_ROUTE ? "route" : L.type == L_SHORTCUT ? "shortcut" : "layer");
+            }
         }
     }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].head) c->layers[i].pair = false;        // heads are fp32
     if (c->rows == 0) return fail(c, YOLO_ERR_INVALID, "cfg has no [yolo] / [region] / [detection] head");
     c->in_mul = (float)atof(opt_s(net, "yolo_input_mul", "1").c_str()); c->in_add = (float)atof(opt_s(net, "yolo_input_add", "0").c_str());
     if (c->rows > 32768) return fail(c, YOLO_ERR_UNSUPPORTED, "more than 32768 candidates per image");
@@ -204,25 +214,46 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         Layer &L = c->layers[i];
         if (L.type == L_SHORTCUT && !c->keep_layers) {
             Layer &P = c->layers[i - 1];
-            if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1 && (L.in[1] < 0 || c->layers[L.in[1]].store_dt == P.store_dt)) { P.residual_from = L.in[1]; L.noop = true; }
+            if (P.type == L_CONV && uses[i - 1] == 1 && !P.head && L.in[1] != i - 1 && (L.in[1] < 0 || c->layers[L.in[1]].store_dt == P.store_dt)) {
+                if (c->pair_of(L.in[1]) != P.pair) return fail(c, YOLO_ERR_INVALID, "layer %d: the conv in front of this shortcut and its other operand are stored in different forms (yolo_pair)", i);
+                P.residual_from = L.in[1]; L.noop = true;
+            }
         }
     }
     // fused stem: conv0 (3x3/s1, 3 -> 32) read only by conv1 (3x3/s2, 32 -> 64), bf16, nothing asking for layer 0's tensor
     // (the stem and halo kernels address their input with 32-bit buffer offsets: the whole-batch window must stay under 2 GiB)
     // (an e4m3 network whose first layers are stored in a 16-bit type -- a mixed plan, yolo_store=bf16 -- runs them through the same fused
     //  kernels: what counts is the type of the tensors a kernel touches, not the context's)
-    const bool ctx16 = c->half_like() || c->dtype == YOLO_FP8;
+    const bool ctx16 = c->half_like() || c->dtype == YOLO_FP8 || c->split();        // (a split-fp16 network: where the tensors a fused kernel touches are PLAIN fp16 -- mixed plans)
     auto is16 = [](int dt) { return dt == DT_BF16 || dt == DT_F16; };
+    // fused residual block (conv_block.hip, conv_block64.hip): a 1x1 conv C -> C/2 read only by the 3x3 conv C/2 -> C that follows, whose folded
+    // shortcut source is the 1x1's own input, on a grid that is (nearly) whole 13 x 13 blocks: C = 128, darknet-53's 104 x 104 stage at
+    // 416 x 416, and (round 5) C = 64, its first residual block at 208 x 208 -- found BEFORE the stem's 1x1 tail and the halo-staged 32 -> 64
+    // form, which would otherwise take those two layers
+    if (ctx16 && !c->keep_layers && !getenv("YOLO_NO_RESBLOCK"))
+        for (int i = 1; i + 1 < NL; ++i) {
+            Layer &A = c->layers[i], &B = c->layers[i + 1];
+            const bool c128 = A.cin == 128 && A.filters == 64 && B.cin == 64 && B.filters == 128;
+            // (C = 64: built and bit-identical, but SLOWER than what it replaces -- 130 us against 107 for the halo-staged 32 -> 64 conv, the stem no
+            //  faster without its 1x1 tail: the block is instruction-issue-bound, ~800 instructions per wave and block for 62 MFMAs, docs/NOTEBOOK.md
+            //  round 5 -- so it is opt-in: YOLO_RESBLOCK64=1)
+            const bool c64 = A.cin == 64 && A.filters == 32 && B.cin == 32 && B.filters == 64 && getenv("YOLO_RESBLOCK64") && !getenv("YOLO_NO_RESBLOCK64");
+            if (A.type == L_CONV && B.type == L_CONV && !A.fc && !B.fc && !A.head && !B.head && uses[i] == 1 && B.in[0] == i && A.in[0] >= 0 &&
+                A.size == 1 && A.stride == 1 && A.pad == 0 && (c128 || c64) && A.residual_from < -1 &&
+                B.size == 3 && B.stride == 1 && B.pad == 1 && B.residual_from == A.in[0] &&
+                ((long)((B.H + 12) / 13) * ((B.W + 12) / 13) * 169 * 100 <= (long)B.H * B.W * 115) && A.in_dt == B.in_dt && (A.in_dt == DT_BF16 || A.in_dt == DT_F16) && A.store_dt == A.in_dt && B.store_dt == A.in_dt &&
+                c->layers[A.in[0]].store_dt == A.in_dt && !A.pair && !B.pair && !c->pair_of(A.in[0])) { A.blk_skip = true; B.blk = true; }
+        }
     if (ctx16 && !c->keep_layers && NL >= 2 && !getenv("YOLO_NO_STEM") && (double)c->max_batch * c->in_h * c->in_w * 8 * 2 < 2147483648.0) {
         const Layer &A = c->layers[0], &B = c->layers[1];
         if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 &&
             A.filters == 32 && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && B.residual_from < -1 &&
-            is16(A.in_dt) && A.store_dt == A.in_dt && B.in_dt == A.in_dt && B.store_dt == A.in_dt) {        // (layer 0 reads the staged image, which is kept in its operand type)
+            is16(A.in_dt) && A.store_dt == A.in_dt && B.in_dt == A.in_dt && B.store_dt == A.in_dt && !c->in_pair && !A.pair && !B.pair) {        // (layer 0 reads the staged image, which is kept in its operand type)
             c->layers[0].stem_skip = true; c->layers[1].stem = true;
             if (NL >= 3) {
                 const Layer &T = c->layers[2];
                 if (T.type == L_CONV && !T.fc && T.in[0] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters == 32 && !T.head && T.residual_from < -1 &&
-                    T.in_dt == A.in_dt && T.store_dt == A.in_dt)
+                    T.in_dt == A.in_dt && T.store_dt == A.in_dt && !T.blk_skip && !T.pair)        // (blk_skip: the fused first residual block computes it)
                     c->layers[2].stem_tail = true;
             }
         }
@@ -230,33 +261,24 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     if (ctx16 && !getenv("YOLO_NO_HALO"))
         for (int i = 1; i < NL; ++i) {
             Layer &L = c->layers[i];
-            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64 &&
-                is16(L.in_dt) && L.store_dt == L.in_dt && (L.residual_from < 0 || c->layers[L.residual_from].store_dt == L.in_dt))
+            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && !L.blk && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64 &&
+                is16(L.in_dt) && L.store_dt == L.in_dt && (L.residual_from < 0 || c->layers[L.residual_from].store_dt == L.in_dt) && !L.pair && !c->pair_of(L.in[0]))
                 L.halo = true;
-        }
-    // fused residual block (conv_block.hip): a 1x1 conv 128 -> 64 read only by the 3x3 conv 64 -> 128 that follows, whose folded shortcut
-    // source is the 1x1's own input, on a grid that is whole 13 x 13 blocks (darknet-53's 104 x 104 stage at 416 x 416)
-    if (ctx16 && !c->keep_layers && !getenv("YOLO_NO_RESBLOCK"))
-        for (int i = 1; i + 1 < NL; ++i) {
-            Layer &A = c->layers[i], &B = c->layers[i + 1];
-            if (A.type == L_CONV && B.type == L_CONV && !A.fc && !B.fc && !A.head && !B.head && uses[i] == 1 && B.in[0] == i && A.in[0] >= 0 &&
-                A.size == 1 && A.stride == 1 && A.pad == 0 && A.cin == 128 && A.filters == 64 && A.residual_from < -1 &&
-                B.size == 3 && B.stride == 1 && B.pad == 1 && B.cin == 64 && B.filters == 128 && B.residual_from == A.in[0] &&
-                ((long)((B.H + 12) / 13) * ((B.W + 12) / 13) * 169 * 100 <= (long)B.H * B.W * 115) && A.in_dt == B.in_dt && (A.in_dt == DT_BF16 || A.in_dt == DT_F16) && A.store_dt == A.in_dt && B.store_dt == A.in_dt) { A.blk_skip = true; B.blk = true; }
         }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
-    if ((c->half_like() || c->dtype == YOLO_FP8) && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
+    if (ctx16 && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
             if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || P.blk || (P.filters != 128 && P.filters != 256)) continue;
+            if (c->split() && (P.pair || c->pair_of(P.in[0]))) continue;       // (split-fp16 networks: the tail rides on plain fp16 layers only)
             int o = i;
             if (P.residual_from >= -1) o = i + 1;            // its shortcut was folded into it: consumers read layer i+1
             const int j = o + 1;
             if (j >= NL) continue;
             Layer &T = c->layers[j];
             if (T.type == L_CONV && !T.fc && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
-                T.residual_from < -1 && !T.stem_tail && !T.blk_skip && T.in_dt == P.in_dt) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
+                T.residual_from < -1 && !T.stem_tail && !T.blk_skip && T.in_dt == P.in_dt && !T.pair) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
         }
     }
     // storage assignment: st_of[i] = storage holding layer i's output
@@ -267,7 +289,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         int off = 0;
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
-            bool ok = !c->split() && j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&      // (split fp16: a concatenation is copied, block by block)
+            bool ok = !L.pair && j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&      // (split fp16: a concatenation is copied, block by block)
                       c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % gran_of(L.store_dt) == 0) && (off % gran_of(L.store_dt) == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
@@ -284,7 +306,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.type == L_ROUTE && L.in.size() >= 2) {
-            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (c->split() ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (L.pair ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
         }
     }
     for (int i = 0; i < NL; ++i) {
@@ -295,7 +317,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
-        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (c->split() ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (L.pair ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
     }
     // a conv whose shortcut was fused writes the shortcut layer's tensor
     for (int i = 0; i + 1 < NL; ++i) {
@@ -354,7 +376,7 @@ int allocate(yolo_ctx *c)
     }
     // network input: 3 real channels padded to 8
     c->input.dt = c->dtype == YOLO_FP32 ? DT_F32 : (c->dtype == YOLO_FP16 || c->split()) ? DT_F16 : DT_BF16;            // fp8 mode keeps the image in bf16
-    const int in_stride = c->split() ? 24 : 8;                 // split fp16: hi | lo | hi blocks of the 8 padded channels
+    const int in_stride = c->in_pair ? 24 : 8;                 // split fp16: hi | lo | hi blocks of the 8 padded channels
     size_t in_bytes = (size_t)c->max_batch * c->in_h * c->in_w * in_stride * dt_size(c->input.dt);
     HIPCK(c, hipMalloc(&c->input.ptr, in_bytes)); HIPCK(c, hipMemsetAsync(c->input.ptr, 0, in_bytes, c->stream));      // defined even if a timing pass runs before any image was staged
     c->input.n = c->max_batch; c->input.h = c->in_h; c->input.w = c->in_w; c->input.c = 8; c->input.stride = in_stride;

@@ -18,10 +18,13 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     TView in = view_of(c, L.in[0]);
     a.in = in.ptr; a.in_stride = in.stride; a.wt = L.d_w; a.bias = L.d_b;
     a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_dt = L.out.dt; a.in_dt = L.in_dt; a.oscale = L.d_sc;
-    if (c->split()) { a.split = 1; a.out_blk = L.out.dt == DT_F32 ? 0 : L.out.stride / 3; }      // split fp16: 16-bit outputs go out as hi | lo | hi blocks
+    // split fp16: a conv that writes PAIRS leaves through the SPLIT epilogue (hi | lo | hi blocks); the fp32 heads of such a network keep
+    // running on the split instantiations too (their tile table); a conv that writes plain fp16 (mixed plans) is the ordinary fp16 kernel,
+    // whatever its input's form -- the K loop only sees 3 x the channels
+    if (L.pair || (c->split() && L.out.dt == DT_F32)) { a.split = 1; a.out_blk = L.out.dt == DT_F32 ? 0 : L.out.stride / 3; }
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
-    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; a.res_blk = c->split() ? r.stride / 3 : 0; }
+    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; a.res_blk = c->pair_of(L.residual_from) ? r.stride / 3 : 0; }
     // the tail runs on the producer's operand type: bf16 needs the fragment-order copy of the 1x1 filters (tail_fragments), e4m3 an
     // e4m3-packed 1x1 conv; anything else leaves w2 null and run_layer refuses the plan instead of launching with a null w2f
     if (L.tail_on && L.tail_layer >= 0 && c->layers[L.tail_layer].in_dt == L.in_dt && (L.in_dt == DT_FP8 || c->layers[L.tail_layer].d_wf)) {
@@ -106,8 +109,8 @@ int run_layer(yolo_ctx *c, int i, int n)
             b.x = x.ptr; b.x_stride = x.stride; b.w1 = A.d_w; b.b1 = A.d_b; b.Kpad1 = A.kpad; b.act1 = A.act;
             b.w2 = B.d_w; b.b2 = B.d_b; b.Kpad2 = B.kpad; b.act2 = B.act; b.out = B.out.ptr; b.out_stride = B.out.stride;
             b.N = n; b.H = B.H; b.W = B.W; b.C = B.filters; b.Cmid = A.filters; b.dt = B.in_dt;
-            if (conv_resblock_ok(b)) {
-                if (L.blk) HIPCK(c, launch_conv_resblock(b, s));
+            if (b.C == 64 ? conv_resblock64_ok(b) : conv_resblock_ok(b)) {
+                if (L.blk) HIPCK(c, b.C == 64 ? launch_conv_resblock64(b, s) : launch_conv_resblock(b, s));
                 break;
             }
         }
@@ -121,7 +124,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             if (conv_halo_ok(h)) { HIPCK(c, launch_conv_halo(h, s)); break; }
             // window over 2 GiB (very large batches): the tiled kernel below checks its own window
         }
-        if (c->split()) {
+        if (a.split) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_split_ok(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
             if (conv_cfg_is_halo(cfg) && (!conv_halo13_ok(a) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
@@ -141,7 +144,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         }
         break; }
     case L_SHORTCUT:
-        if (!L.noop && c->split()) {
+        if (!L.noop && L.pair) {
             HIPCK(c, launch_add_split(view_of(c, L.in[0]).ptr, view_of(c, L.in[1]).ptr, L.out.ptr, L.out.stride / 3, (size_t)n * L.H * L.W, s));
         } else if (!L.noop) {
             float sa = 1.f, sb = 1.f, so = 1.f;
@@ -154,7 +157,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             TView src = nview(view_of(c, L.copy_inputs[k])); TView dst = nview(L.out);
             dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * dt_size(dst.dt); dst.c = src.c;
             if (src.c % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of %d channels", src.c);
-            if (c->split()) {        // three blocks of the source into the three blocks of the concatenation
+            if (L.pair) {        // three blocks of the source into the three blocks of the concatenation
                 const int cps = src.stride / 3, cpd = L.out.stride / 3;
                 for (int blk = 0; blk < 3; ++blk) {
                     TView sv = src, dv = nview(L.out);
@@ -168,9 +171,9 @@ int run_layer(yolo_ctx *c, int i, int n)
         }
         break;
     case L_LOCAL: HIPCK(c, launch_local(nview(view_of(c, L.in[0])), nview(L.out), L.d_w, L.d_b, L.size, L.stride, L.pad, L.act, s)); break;
-    case L_UPSAMPLE: if (c->split()) { if (int r = via_f32(c, L, n, 0)) return r; break; } HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
-    case L_MAXPOOL: if (c->split()) { if (int r = via_f32(c, L, n, 1)) return r; break; } HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
-    case L_REORG: if (c->split()) { if (int r = via_f32(c, L, n, 2)) return r; break; } HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
+    case L_UPSAMPLE: if (L.pair) { if (int r = via_f32(c, L, n, 0)) return r; break; } HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
+    case L_MAXPOOL: if (L.pair) { if (int r = via_f32(c, L, n, 1)) return r; break; } HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
+    case L_REORG: if (L.pair) { if (int r = via_f32(c, L, n, 2)) return r; break; } HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
     case L_DETECT: {
         const Layer &P = c->layers[i - 1];
         HIPCK(c, launch_decode_v1((const float *)P.out.ptr, P.out.stride, n, L.side, L.na, L.classes, L.sqr, c->d_det, c->rows, L.row_off,
@@ -234,7 +237,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
         c->stem_u8 = (const uint8_t *)src; c->stem_scale = scale; c->stem_u8_n = n;
         return YOLO_OK;
     }
-    if (c->split()) {        // the image in fp32 (exact for uint8 pixels x scale up to fp32 rounding), then split pairs
+    if (c->in_pair) {        // the image in fp32 (exact for uint8 pixels x scale up to fp32 rounding), then split pairs
         HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->d_f32a, DT_F32, 8, c->stream, c->in_mul, c->in_add));
         HIPCK(c, launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, npix, c->stream));
         return YOLO_OK;
@@ -335,9 +338,9 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
         HIPCK(c, hipMemcpyAsync(tmp, image, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream)); src = (const uint8_t *)tmp;
     }
     c->stem_u8 = nullptr;
-    hipError_t e = c->split() ? launch_resize_u8(src, h, w, c->in_h, c->d_f32a, DT_F32, 8, 8, c->stream, c->in_mul, c->in_add)
+    hipError_t e = c->in_pair ? launch_resize_u8(src, h, w, c->in_h, c->d_f32a, DT_F32, 8, 8, c->stream, c->in_mul, c->in_add)
                               : launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
-    if (e == hipSuccess && c->split()) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
+    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -357,8 +360,8 @@ int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h
         HIPCK(c, hipMemcpyAsync(tmp, image_chw, (size_t)h * w * 3 * 4, hipMemcpyHostToDevice, c->stream)); src = (const float *)tmp;
     }
     c->stem_u8 = nullptr;
-    hipError_t e = c->split() ? launch_letterbox_chw(src, w, h, c->in_h, c->d_f32a, DT_F32, 8, c->stream) : launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
-    if (e == hipSuccess && c->split()) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
+    hipError_t e = c->in_pair ? launch_letterbox_chw(src, w, h, c->in_h, c->d_f32a, DT_F32, 8, c->stream) : launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
+    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "letterbox: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -520,20 +523,20 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     const int NL = (int)c->layers.size();
     auto shape_key = [&](const Layer &L) {
         ConvArgs a = conv_args(c, L, n);
-        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d%d_%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.in_dt, a.out_dt, a.res != nullptr);
+        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d%d_%d%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.in_dt, a.out_dt, a.res != nullptr, a.split);
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
         if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
-        if (c->split()) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo13_ok(a) && a.out_dt != DT_F32));
+        if (a.split) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo13_ok(a) && a.out_dt != DT_F32));
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
     for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = c->split() ? split_default_cfg(a) : conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = a.split ? split_default_cfg(a) : conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {

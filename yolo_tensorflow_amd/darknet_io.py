@@ -449,6 +449,91 @@ def synth_weights_log(secs, seed=0, obj_bias=-0.75, real=None):
     return np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for q in parts]).astype(np.float32)
 
 
+def pair_closure(secs, want):
+    """Mixed fp16 / split-fp16 plans: `want` is a set of layer indices (-1 = the network input) whose tensors should be
+    stored as split-fp16 pairs.  Only [convolutional] sections (and the image) carry the choice -- layers that move data (shortcut, route,
+    upsample, pooling, reorg) inherit their operands' form, as on the device (csrc/yolo_plan.cpp) --, and both operands of a shortcut / all
+    inputs of a concatenation must share one form: the set is grown until it is closed.  Heads ([yolo] producers) are fp32, never pairs.
+    Returns {layer index: bool} for every layer and -1."""
+    L = secs[1:]
+    S = set(int(l) for l in want if int(l) < 0 or L[int(l)]["type"] == "convolutional")
+
+    def inputs(i):
+        s = L[i]; t = s["type"]
+        if t == "shortcut":
+            f = int(s["from"]); return [i - 1, f if f >= 0 else i + f]
+        if t == "route":
+            return [int(x) if int(x) >= 0 else i + int(x) for x in s["layers"].split(",")]
+        return [i - 1]
+
+    def head(i):
+        return i >= 0 and i + 1 < len(L) and L[i + 1]["type"] in ("yolo", "region", "detection")
+
+    def is_pair(i):
+        if i < 0:
+            return -1 in S
+        t = L[i]["type"]
+        if t in ("convolutional", "connected", "local"):
+            return i in S and not head(i)
+        if t in ("yolo", "region", "detection"):
+            return False
+        return is_pair(inputs(i)[0])
+
+    def force(i):
+        if i < 0 or L[i]["type"] == "convolutional":
+            S.add(i)
+        elif L[i]["type"] not in ("yolo", "region", "detection"):
+            for j in inputs(i):
+                force(j)
+
+    for l in want:                        # a mover asked for: its producers
+        if int(l) >= 0 and L[int(l)]["type"] != "convolutional":
+            force(int(l))
+    changed = True
+    while changed:
+        changed = False
+        for i, s in enumerate(L):
+            if s["type"] == "shortcut" or (s["type"] == "route" and "," in s["layers"]):
+                flags = [is_pair(j) for j in inputs(i)]
+                if any(flags) and not all(flags):
+                    for j in inputs(i):
+                        force(j)
+                    changed = True
+    return {i: is_pair(i) for i in range(-1, len(L))}
+
+
+def with_layer_pairs(text, pair):
+    """cfg text of a split-fp16 (YOLO_FP16X2) network with the storage form of every tensor written out: `yolo_pair=0` on the [convolutional]
+    sections whose output is PLAIN fp16 and `yolo_pair_input=0` in [net] when the image is, per `pair` = pair_closure(secs, want)
+    ({layer index: bool}); sections not mentioned stay pairs (the device's default).  The convs that read a plain tensor then run one MFMA
+    product per algorithmic one instead of three, and the fused kernels of the fp16 configuration serve the plain stretches."""
+    out, idx = [], -2
+    for line in text.splitlines():
+        t = line.strip()
+        if t.split("=")[0].strip() in ("yolo_pair", "yolo_pair_input"):
+            continue
+        out.append(line)
+        if t.startswith("["):
+            idx += 1
+            name = t[1:t.index("]")].strip()
+            if idx == -1 and not pair.get(-1, True):
+                out.append("yolo_pair_input=0")
+            elif idx >= 0 and name == "convolutional" and not pair.get(idx, True):
+                out.append("yolo_pair=0")
+    return "\n".join(out) + "\n"
+
+
+def pair_flop_share(secs, pair):
+    """Share of the conv FLOPs whose conv reads a tensor stored as pairs (three MFMA products per algorithmic one)."""
+    shapes = layer_shapes(secs)
+    tot = three = 0.0
+    for i, s in enumerate(secs[1:]):
+        if s["type"] == "convolutional":
+            f = 2.0 * int(s["size"]) ** 2 * shapes[i][4] * int(s["filters"]) * shapes[i][1] * shapes[i][2]
+            tot += f; three += f if pair.get(i - 1, False) else 0.0
+    return three / tot
+
+
 def default_header(secs):
     """(major, minor) the reference's files carry: v3 family -> (0,2) 64-bit seen; region (v2) -> (0,1)."""
     return (0, 2) if any(s["type"] == "yolo" for s in secs) else (0, 1)
