@@ -186,7 +186,7 @@ PLANS = os.path.join(os.path.dirname(ROOT), "yolo_tensorflow_amd", "tuned")
 # reference's own vectors (round 5)
 # (the `real` stand-in on NOISE images is in its amplifying regime throughout -- 42 611 candidates against 18 744 on `log` --, like person.jpg
 #  among the natural ones: bf16 measured 0.056 / 0.52 with 3 338 candidates lost)
-FLOOR32 = {("log", "bf16"): (0.48, 0.30), ("log", "fp16"): (0.90, 0.04), ("real", "bf16"): (0.04, 0.60), ("real", "fp16"): (0.0, 1.0)}
+FLOOR32 = {("log", "bf16"): (0.48, 0.30), ("log", "fp16"): (0.90, 0.04), ("real", "bf16"): (0.04, 0.60), ("real", "fp16"): (0.65, 0.13)}       # (real: measured 0.056 / 0.52 and 0.698 / 0.110, 198 lost)
 
 
 @pytest.mark.parametrize("stats", ["log", "real"])
