@@ -5,7 +5,7 @@
 set -u
 # SIZE / BATCH (default 416 / 32 = the headline workload) select another workload, e.g. SIZE=608 BATCH=8 bash tools/profile_round.sh r04_608_b8
 # (BASELINE config 4's per-GPU share): the bf16 line, its kernel trace and the PMC passes only.
-R=${1:-r04}
+R=${1:-r05}
 export SIZE=${SIZE:-416} B=${BATCH:-32}
 W="--size $SIZE --batch $B"
 OUT=gpurun_out/prof_$R
@@ -18,8 +18,9 @@ python3 bench.py --dtype mixed --no-cpu-baseline --parity-images 2 > "$OUT/bench
 python3 bench.py --dtype fp16 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp16.json" 2> "$OUT/bench_fp16.err"
 python3 bench.py --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"
 python3 bench.py --dtype fp16x2 --steps 20 --warmup 5 --no-cpu-baseline --parity-images 2 > "$OUT/bench_fp16x2.json" 2> "$OUT/bench_fp16x2.err"
+python3 bench.py --dtype mixed16 --steps 20 --warmup 5 --no-cpu-baseline --parity-images 2 > "$OUT/bench_mixed16.json" 2> "$OUT/bench_mixed16.err"
 # kernel-level traces of the other storage types (per-kernel calls / average duration: the rooflines of those lines can be recomputed from them)
-for DT in fp8 mixed fp16x2; do
+for DT in fp8 mixed fp16x2 mixed16; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$DT" -o bench -- python3 bench.py --dtype $DT --no-cpu-baseline --parity-images 0 --steps 20 --warmup 5 > "$OUT/bench_${DT}_under_rocprof.json" 2> "$OUT/stats_$DT.err"
 done
 else

@@ -19,8 +19,8 @@ def last_json(path):
     return json.loads(line) if line else None
 
 
-for name in ("bench.json", "bench_fp8.json", "bench_mixed.json", "bench_fp16.json", "bench_fp32.json", "bench_fp16x2.json", "bench_under_rocprof.json",
-             "bench_fp8_under_rocprof.json", "bench_mixed_under_rocprof.json", "bench_fp16x2_under_rocprof.json"):
+for name in ("bench.json", "bench_fp8.json", "bench_mixed.json", "bench_fp16.json", "bench_fp32.json", "bench_fp16x2.json", "bench_mixed16.json", "bench_under_rocprof.json",
+             "bench_fp8_under_rocprof.json", "bench_mixed_under_rocprof.json", "bench_fp16x2_under_rocprof.json", "bench_mixed16_under_rocprof.json"):
     j = last_json(os.path.join(src, name)) if os.path.exists(os.path.join(src, name)) else None
     if j:
         json.dump(j, open(os.path.join(dst, "%s_%s" % (R, name)), "w"), indent=1)
@@ -28,7 +28,7 @@ for name in ("bench.json", "bench_fp8.json", "bench_mixed.json", "bench_fp16.jso
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True) or glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(dst, "%s_bench_kernel_stats.csv" % R))
-for dt in ("fp8", "mixed", "fp16x2"):
+for dt in ("fp8", "mixed", "fp16x2", "mixed16"):
     sd = glob.glob(os.path.join(src, "stats_%s" % dt, "**", "*kernel_stats.csv"), recursive=True)
     if sd:
         shutil.copy(sd[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (R, dt)))

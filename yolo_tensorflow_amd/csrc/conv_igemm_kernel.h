@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         if (is_loader) {
 #pragma unroll
             for (int i = 0; i < LAH; ++i)
-                if (wid + i * NW < APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(smem + (wid + i * NW) * 1024), 16, aoff[i], 0, 0, 0);
+                if (wid + i * NW < APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(smem + (wid + i * NW) * 1024), 16, aoff[i], 0, 0, HALO_LOAD_AUX);
 #pragma unroll
             for (int t = 1; t < (FREE ? NS - 1 : 1); ++t)        // (stage 0 was requested ahead of the halo addressing)
                 if (t < KT) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             }
             if constexpr (TAP < LAH)
                 if (load_a && wid + TAP * NW < APIECES)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(fill_a + (wid + TAP * NW) * 1024), 16, aoff[TAP], next_chunk * RB, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(fill_a + (wid + TAP * NW) * 1024), 16, aoff[TAP], next_chunk * RB, 0, HALO_LOAD_AUX);
         }
         __builtin_amdgcn_s_setprio(2);
         mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HP + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         const int ops_now = (do_a ? 1 : 0) + (load_f ? LB : 0);
         auto issue = [&]() {
             if constexpr (ATAP)
-                if (do_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(fill_a + (wid + TAP * NW) * 1024), 16, aoff[TAP < LAH ? TAP : 0], next_chunk * RB, 0, 0);
+                if (do_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(fill_a + (wid + TAP * NW) * 1024), 16, aoff[TAP < LAH ? TAP : 0], next_chunk * RB, 0, HALO_LOAD_AUX);
             if (load_f) {
 #pragma unroll
                 for (int i = 0; i < LB; ++i)
@@ -770,8 +770,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     int r2, c2;
                     unsigned ro = piece_off(tid + it * NT, CPRH, 8, res_sb, r2, c2);
                     ro = off == OOB_OFFSET ? OOB_OFFSET : ro + (unsigned)(HALF * HC * 2);
-                    rh[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0);
-                    rl[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro == OOB_OFFSET ? OOB_OFFSET : ro + rblk, 0, 0);
+                    rh[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, RES_LOAD_AUX);
+                    rl[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro == OOB_OFFSET ? OOB_OFFSET : ro + rblk, 0, RES_LOAD_AUX);
                 }
             }
             block_barrier();                                  // the stages (half 0) / the previous half's tile (half 1) are no longer read
@@ -838,13 +838,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 #pragma unroll
                 for (int it = 0; it < NIT8; ++it) {
                     int row, cc;
-                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR8, 16, res_sb, row, cc), 0, 0);
+                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR8, 16, res_sb, row, cc), 0, RES_LOAD_AUX);
                 }
             } else {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     int row, cc;
-                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR, 8, res_sb, row, cc), 0, 0);
+                    rpre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(tid + it * NT, CPR, 8, res_sb, row, cc), 0, RES_LOAD_AUX);
                 }
             }
         }
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 }
                 float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
                 if (oq >= 0) a.obj_out[(size_t)m * a.obj_na + oan] = oq == 0 ? v[0] : oq == 1 ? v[1] : oq == 2 ? v[2] : v[3];
-                if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
+                if (ch + 3 < a.Cout) out_store16(o, __builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
                 else
                     for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];
             }

@@ -7,6 +7,14 @@
 #ifndef OUT_STORE_AUX
 #define OUT_STORE_AUX 16
 #endif
+// probe knobs (tools/probe/ab), 0 = default policy in the shipped library: cache policy of the halo-staged form's activation tile loads
+// (each byte is read once per workgroup) and of the epilogue's shortcut loads (read once)
+#ifndef HALO_LOAD_AUX
+#define HALO_LOAD_AUX 0
+#endif
+#ifndef RES_LOAD_AUX
+#define RES_LOAD_AUX 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 // the same policy for a 16-byte store through a plain pointer (kernels that do not hold a buffer descriptor for their output)
