@@ -347,3 +347,30 @@ def test_halo_form_on_ragged_blocks_equals_tiled_form(hiplib, dtype):
     x = rng.standard_normal((1, 19, 19, cin)).astype(np.float32)
     with pytest.raises(hiplib.YoloError, match="not applicable"):
         hiplib.op_conv2d(x, (rng.standard_normal((3, 3, cin, 128)) * 0.05).astype(np.float32), None, dtype=dt, tile_cfg=40)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_halo_form_on_rectangular_blocks_equals_tiled_form(hiplib, dtype):
+    """Round 5: the free-running halo form on 10 x 19 blocks (tile configurations 54: x 256 channels, 55: x 128) and 5 x 19 strips (56: x 128) --
+    what tiles the 608 x 608 network's 76 / 38 / 19 grids into exactly 256 workgroups at 8 images per GPU -- against
+    the tiled form: bit for bit (same K order), with and without the fused shortcut, on the grids they are for, on grids where the last
+    block row is ragged (76 = 8 x 10 - 4, 38 = 4 x 10 - 2, 19 = 4 x 5 - 1) and on ragged columns too (37 x 37); a grid they would waste more
+    than 15 % of is refused, and so are e4m3 operands."""
+    dt = {"bf16": hiplib.BF16, "fp16": hiplib.FP16}[dtype]
+    rng = np.random.default_rng(7)
+    for (n, h, cin, cout, cfgs) in ((2, 76, 128, 256, (54, 55, 56)), (3, 38, 256, 512, (54, 55, 56)), (3, 19, 128, 256, (54, 55, 56)), (1, 37, 64, 128, (55, 56)), (2, 57, 64, 128, (55, 56))):
+        x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+        w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((n, h, h, cout)).astype(np.float32)
+        for r in (None, res):
+            want = hiplib.op_conv2d(x, w, b, act=1, residual=r, dtype=dt, tile_cfg=16)
+            for cfg in cfgs:
+                got = hiplib.op_conv2d(x, w, b, act=1, residual=r, dtype=dt, tile_cfg=cfg)
+                assert np.array_equal(got, want), (dtype, h, cout, cfg, r is not None)
+    x = rng.standard_normal((1, 13, 13, 128)).astype(np.float32)          # 13 x 13 under 10 x 19 blocks: 2 x 1 blocks of 190 for 169 pixels = 2.2 x
+    w = (rng.standard_normal((3, 3, 128, 128)) * 0.05).astype(np.float32)
+    with pytest.raises(hiplib.YoloError, match="not applicable"):
+        hiplib.op_conv2d(x, w, None, dtype=dt, tile_cfg=54)
+    with pytest.raises(hiplib.YoloError):
+        hiplib.op_conv2d(rng.standard_normal((1, 19, 19, 128)).astype(np.float32), w, None, dtype=hiplib.FP8, tile_cfg=56)

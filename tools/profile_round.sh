@@ -21,17 +21,17 @@ python3 bench.py --dtype fp16x2 --steps 20 --warmup 5 --no-cpu-baseline --parity
 python3 bench.py --dtype mixed16 --steps 20 --warmup 5 --no-cpu-baseline --parity-images 2 > "$OUT/bench_mixed16.json" 2> "$OUT/bench_mixed16.err"
 # kernel-level traces of the other storage types (per-kernel calls / average duration: the rooflines of those lines can be recomputed from them)
 for DT in fp8 mixed fp16x2 mixed16; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$DT" -o bench -- python3 bench.py --dtype $DT --no-cpu-baseline --parity-images 0 --steps 20 --warmup 5 > "$OUT/bench_${DT}_under_rocprof.json" 2> "$OUT/stats_$DT.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$DT" -o bench -- python3 bench.py --dtype $DT --no-cpu-baseline --no-latency --parity-images 0 --steps 20 --warmup 5 > "$OUT/bench_${DT}_under_rocprof.json" 2> "$OUT/stats_$DT.err"
 done
 else
 python3 bench.py $W --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py $W --no-cpu-baseline --parity-images 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     D="$OUT/pmc_$(echo $C | cut -d' ' -f1)"
     ITERS=2 timeout 600 rocprofv3 --pmc $C --output-format csv -d "$D" -o p -- python3 tools/prof_forward.py > "$D.log" 2>&1
 done
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $W --no-cpu-baseline --parity-images 0 --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
 python3 tools/step_timeline.py "$OUT/trace" > "$OUT/step_timeline.txt" 2>&1
 python3 tools/summarize_profile.py "$OUT" "$R" "$OUT/summary"
 cp "$OUT/step_timeline.txt" "$OUT/summary/${R}_step_timeline.txt"

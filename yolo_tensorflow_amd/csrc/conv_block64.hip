@@ -138,11 +138,46 @@ __global__ __launch_bounds__(64 * B6_NW, 4) void conv_resblock_c64(const BlockAr
         mida[j] = (uint32_t)(uintptr_t)(b6_lds_char *)lmo_ + (uint32_t)((oy * B6_T + ox) * B6_MPITCH + lq * 16);
         asm volatile("" : "+v"(mida[j]));
     }
+    // ---- INTERIOR blocks (the 15 x 15 halo window lies inside the image: 196 of the 256 blocks of a 208 x 208 image): every address is a
+    //      per-lane constant plus one scalar per block, passed as the buffer instruction's soffset -- no per-block vector address arithmetic ----
+    const int fcl = lane >> 3, fchunk = lane & 7;
+    unsigned foff[4];                                   // this wave's halo pieces id = wave + 8 i: byte offset from the window's first pixel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = wave + i * B6_NW, r = id >> 1, c = (id & 1) * 8 + fcl;
+        foff[i] = (unsigned)(((r * a.W + c) * a.x_stride + ((fchunk ^ ((c - r) & 7)) * 8)) * 2);
+    }
+    unsigned soff[B6_NPIECE], xlds[B6_NPIECE];           // this thread's output pieces: byte offset from the block's first pixel; LDS address of the shortcut piece
+    unsigned plds0;                                      // LDS address of its first staged piece (piece k: + k * 64 rows)
+    {
+#pragma unroll
+        for (int k = 0; k < B6_NPIECE; ++k) {
+            const int g = tid + k * 64 * B6_NW, px = g >> 3, piece = g & 7;
+            const bool in = px < B6_OPIX;
+            const int oy = in ? (px * 5042) >> 16 : 0, ox = in ? px - oy * B6_B : 0;
+            const int hp = (oy + 1) * B6_T + ox + 1;
+            soff[k] = in ? (unsigned)(((oy * a.W + ox) * a.out_stride + piece * 8) * 2) : 0x80000000u;
+            xlds[k] = (unsigned)(uintptr_t)(b6_lds_char *)lx_ + (unsigned)(hp * B6_XPITCH + ((piece ^ (hp & 7)) << 4));
+        }
+        plds0 = (unsigned)(uintptr_t)(b6_lds_char *)lmo_ + (unsigned)((tid >> 3) * B6_OPITCH + (tid & 7) * 16);
+    }
+    auto interior_of = [&](const Blk &q) { return q.y0 >= 1 && q.x0 >= 1 && q.y0 + B6_B + 1 <= a.H && q.x0 + B6_B + 1 <= a.W; };
+    auto fetch_x_interior = [&](const Blk &q, b6_lds_char *dst) {
+        const unsigned base = (unsigned)(((q.n * a.H + q.y0 - 1) * a.W + q.x0 - 1) * a.x_stride * 2);        // scalar
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = wave + i * B6_NW;
+            if (id < B6_T * 2 && (id & 1) * 8 + fcl < B6_T)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (b6_lds_void *)(dst + ((id >> 1) * B6_T + (id & 1) * 8) * B6_XPITCH), 16, foff[i], base, 0, 0);
+        }
+    };
     // One block.  Every LDS region is its own __restrict__ parameter (see conv_block.hip: hipcc cannot tell an LDS-DMA's target from any
     // other LDS access and would wait vmcnt(0) in front of the first LDS read after every fetch); the barriers order what the parameters hide.
     auto block = [&](int it, const b6_lds_char *__restrict__ lx, b6_lds_char *__restrict__ lx_dma, b6_lds_char *__restrict__ lmid, const b6_lds_char *__restrict__ mid_rd,
-                     const b6_lds_char *__restrict__ lw1, const b6_lds_char *__restrict__ lb1, const b6_lds_char *__restrict__ lb2, b6_lds_char *__restrict__ lout) {
+                     const b6_lds_char *__restrict__ lw1, const b6_lds_char *__restrict__ lb1, const b6_lds_char *__restrict__ lb2, b6_lds_char *__restrict__ lout,
+                     const b6_lds_char *__restrict__ abs_rd) {
         const Blk q = blk_of(it);
+        const bool interior = interior_of(q);             // (scalar)
         // this block's halo tile has landed (first pass: and the 1x1 filters are written): the vector-memory queue is in order, and behind the
         // tile's LDS-DMA this thread issued the previous block's B6_NPIECE stores (every lane issues every one: out-of-range offsets, never a
         // skipped instruction), which may still be in flight
@@ -160,27 +195,27 @@ __global__ __launch_bounds__(64 * B6_NW, 4) void conv_resblock_c64(const BlockAr
             int p0 = (2 * u) * 16 + l15;
             asm volatile("" : "+v"(p0));
             const int p1 = p0 + 16;
-            b6_bf16x8 xf[2][2], wf[2][2];
+            // (one K-step's fragments at a time: stage 1 is where the register peak would be)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                xf[kk][0] = *(lds_frag_p)(lx + p0 * B6_XPITCH + (((kk * 4 + lq) ^ (p0 & 7)) << 4));
-                xf[kk][1] = *(lds_frag_p)(lx + p1 * B6_XPITCH + (((kk * 4 + lq) ^ (p1 & 7)) << 4));
+                b6_bf16x8 xf[2], wf[2];
+                xf[0] = *(lds_frag_p)(lx + p0 * B6_XPITCH + (((kk * 4 + lq) ^ (p0 & 7)) << 4));
+                xf[1] = *(lds_frag_p)(lx + p1 * B6_XPITCH + (((kk * 4 + lq) ^ (p1 & 7)) << 4));
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) wf[kk][ct] = *(lds_frag_p)(lw1 + (ct * 16 + l15) * B6_W1PITCH + (kk * 4 + lq) * 16);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                for (int ct = 0; ct < 2; ++ct) wf[ct] = *(lds_frag_p)(lw1 + (ct * 16 + l15) * B6_W1PITCH + (kk * 4 + lq) * 16);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    acc[0][ct] = b6_mma<H16>(wf[kk][ct], xf[kk][0], acc[0][ct]);
-                    acc[1][ct] = b6_mma<H16>(wf[kk][ct], xf[kk][1], acc[1][ct]);
+                    acc[0][ct] = b6_mma<H16>(wf[ct], xf[0], acc[0][ct]);
+                    acc[1][ct] = b6_mma<H16>(wf[ct], xf[1], acc[1][ct]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int p = s ? p1 : p0;
                 if (2 * u + s >= B6_TSUB) continue;      // (wave-uniform)
                 const int r = (p * 4370) >> 16, col = p - r * B6_T;
-                const bool inside = p < B6_TPIX && (unsigned)(q.y0 - 1 + r) < (unsigned)a.H && (unsigned)(q.x0 - 1 + col) < (unsigned)a.W;
+                const bool inside = p < B6_TPIX && (interior || ((unsigned)(q.y0 - 1 + r) < (unsigned)a.H && (unsigned)(q.x0 - 1 + col) < (unsigned)a.W));
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     uint2 pk = b6_epi<H16>(acc[s][ct], *(const __attribute__((address_space(3))) b6_f32x4 *)(lb1 + (ct * 16 + lq * 4) * 4), slope1);
@@ -195,24 +230,18 @@ __global__ __launch_bounds__(64 * B6_NW, 4) void conv_resblock_c64(const BlockAr
         b6_f32x4 acc2[B6_NJ];
 #pragma unroll
         for (int j = 0; j < B6_NJ; ++j) acc2[j] = b6_f32x4{0.f, 0.f, 0.f, 0.f};
-        // step = (tap, half of the wave's six sub-tiles): the three fragments of step + 1 are requested ahead of the three MFMAs of this step
-        // (registers: two workgroups per CU leave 128 per wave -- 36 of filters, 24 accumulators, 24 of fragments in flight)
-        b6_bf16x8 fg[2][3];
+        // step = (tap, half of the wave's six sub-tiles): three fragments, three MFMAs.  Registers are the constraint (two workgroups per CU
+        // leave 128 per wave: 36 of filters, 24 accumulators, the per-lane address constants of the interior path): the fragments are not
+        // double-buffered -- with four waves per SIMD the other waves' MFMAs cover a step's LDS latency
         auto koff = [](int t) { const int kh = t / 3, kw = t - kh * 3; return (kh * B6_T + kw) * B6_MPITCH; };
-#pragma unroll
-        for (int j = 0; j < 3; ++j) fg[0][j] = *(lds_frag_p)(mid_rd + mida[j] + koff(0));
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 18; ++st) {
             const int t = st >> 1, g = st & 1;
-            if (st + 1 < 18) {
-                const int tn = (st + 1) >> 1, gn = (st + 1) & 1;
+            b6_bf16x8 fg[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) fg[(st + 1) & 1][j] = *(lds_frag_p)(mid_rd + mida[gn * 3 + j] + koff(tn));
-            }
+            for (int j = 0; j < 3; ++j) fg[j] = *(lds_frag_p)(mid_rd + mida[g * 3 + j] + koff(t));
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc2[g * 3 + j] = b6_mma<H16>(fw2[t], fg[st & 1][j], acc2[g * 3 + j]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 3; ++j) acc2[g * 3 + j] = b6_mma<H16>(fw2[t], fg[j], acc2[g * 3 + j]);
         }
         __builtin_amdgcn_s_barrier();                    // every wave is done with the mid tile: the staged output goes over it
         // ================= epilogue =================
@@ -226,41 +255,44 @@ __global__ __launch_bounds__(64 * B6_NW, 4) void conv_resblock_c64(const BlockAr
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();                    // staged tile complete
         // 169 pixels x 8 pieces of 16 bytes; the shortcut is x at the same pixel and channels, still in the x tile
-        // (piece g = tid + 512 k is 16-byte piece (g & 7) of block pixel (g >> 3); its addresses are re-derived here rather than held in
-        //  registers across the block: 128 registers per wave, and one spilled value is ruinous -- conv_block.hip)
+        // (piece g = tid + 512 k is 16-byte piece (g & 7) of block pixel (g >> 3): staged piece k sits 64 rows below piece 0)
         b6_u32x4 o[B6_NPIECE];
 #pragma unroll
         for (int k = 0; k < B6_NPIECE; ++k) {
-            int g = tid + k * 64 * B6_NW;
-            asm volatile("" : "+v"(g));
-            const int px = g >> 3, piece = g & 7;
-            const bool in = px < B6_OPIX;
-            const int oy = in ? (px * 5042) >> 16 : 0, ox = in ? px - oy * B6_B : 0;
-            const int hp = (oy + 1) * B6_T + ox + 1;
-            const b6_u32x4 v = *(const __attribute__((address_space(3))) b6_u32x4 *)(lout + (in ? px : 0) * B6_OPITCH + piece * 16);
-            const b6_u32x4 r = *(const __attribute__((address_space(3))) b6_u32x4 *)(lx + hp * B6_XPITCH + ((piece ^ (hp & 7)) << 4));
+            const bool in = tid + k * 64 * B6_NW < B6_OPIX * 8;
+            const b6_u32x4 v = *(const __attribute__((address_space(3))) b6_u32x4 *)(abs_rd + (in ? plds0 + (unsigned)(k * 64 * B6_OPITCH) : plds0));
+            const b6_u32x4 r = *(const __attribute__((address_space(3))) b6_u32x4 *)(abs_rd + xlds[k]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[k][e] = b6_pk<H16>(b6_lo<H16>(v[e]) + b6_lo<H16>(r[e]), b6_hi<H16>(v[e]) + b6_hi<H16>(r[e]));
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();                    // nobody reads the x tile (or the staged tile) any more
-        if (it + 1 < nt) fetch_x(blk_of(it + 1), lx_dma);        // in flight under the stores below and the co-resident workgroup's block
+        if (it + 1 < nt) {                               // in flight under the stores below and the co-resident workgroup's block
+            const Blk qn = blk_of(it + 1);
+            if (interior_of(qn)) fetch_x_interior(qn, lx_dma); else fetch_x(qn, lx_dma);
+        }
+        if (interior) {
+            const unsigned base = (unsigned)(((q.n * a.H + q.y0) * a.W + q.x0) * a.out_stride * 2);           // scalar
 #pragma unroll
-        for (int k = 0; k < B6_NPIECE; ++k) {
-            int g = tid + k * 64 * B6_NW;
-            asm volatile("" : "+v"(g));
-            const int px = g >> 3, piece = g & 7;
-            const int oy = (px * 5042) >> 16, ox = px - oy * B6_B;
-            const bool ok = px < B6_OPIX && q.y0 + oy < a.H && q.x0 + ox < a.W;
-            const unsigned pix = (unsigned)((q.n * a.H + q.y0 + oy) * a.W + q.x0 + ox);
-            __builtin_amdgcn_raw_buffer_store_b128(o[k], ro, ok ? (pix * a.out_stride + piece * 8) * 2 : 0x80000000u, 0, OUT_STORE_AUX);
+            for (int k = 0; k < B6_NPIECE; ++k) __builtin_amdgcn_raw_buffer_store_b128(o[k], ro, soff[k], base, OUT_STORE_AUX);
+        } else {
+#pragma unroll
+            for (int k = 0; k < B6_NPIECE; ++k) {
+                int g = tid + k * 64 * B6_NW;
+                asm volatile("" : "+v"(g));
+                const int px = g >> 3, piece = g & 7;
+                const int oy = (px * 5042) >> 16, ox = px - oy * B6_B;
+                const bool ok = px < B6_OPIX && q.y0 + oy < a.H && q.x0 + ox < a.W;
+                const unsigned pix = (unsigned)((q.n * a.H + q.y0 + oy) * a.W + q.x0 + ox);
+                __builtin_amdgcn_raw_buffer_store_b128(o[k], ro, ok ? (pix * a.out_stride + piece * 8) * 2 : 0x80000000u, 0, OUT_STORE_AUX);
+            }
         }
     };
-    if (nt > 0) fetch_x(blk_of(0), (b6_lds_char *)lx_);
+    if (nt > 0) { const Blk q0 = blk_of(0); if (interior_of(q0)) fetch_x_interior(q0, (b6_lds_char *)lx_); else fetch_x(q0, (b6_lds_char *)lx_); }
     __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the first halo tile has landed, the 1x1 filters are written
     for (int it = 0; it < nt; ++it)
         block(it, (const b6_lds_char *)lx_, (b6_lds_char *)lx_, (b6_lds_char *)lmo_, (const b6_lds_char *)(uintptr_t)0, (const b6_lds_char *)lw1_, (const b6_lds_char *)lb1_,
-              (const b6_lds_char *)lb2_, (b6_lds_char *)lmo_);
+              (const b6_lds_char *)lb2_, (b6_lds_char *)lmo_, (const b6_lds_char *)(uintptr_t)0);
 #endif
 }
 

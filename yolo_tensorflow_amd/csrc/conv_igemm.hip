@@ -224,10 +224,13 @@ bool conv_cfg_split_ok(int cfg)
     }
 }
 
+// round 5: free-running halo forms on rectangular blocks (conv_halo13.hip): 10 x 19 (12 sub-tiles) x 256 / 128 channels, 5 x 19 (6 sub-tiles) x 128
+// -- the 608 x 608 network's 76 / 38 / 19 grids tile into them exactly, 256 workgroups each at 8 images per GPU
+#define CONV_CFGS_HALO_R(X) X(54, 1, 8, 12, 2, 2, 64, 0) X(55, 1, 8, 12, 1, 3, 64, 0) X(56, 1, 8, 6, 1, 3, 64, 0)
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl, halo; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 0},
 #define XH(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 1},
-static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X)};
+static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X) CONV_CFGS_HALO_R(XH)};
 #undef X
 #undef XH
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
@@ -244,6 +247,7 @@ const char *conv_cfg_name(int cfg)
     static char names[64][32];
     if (cfg < 0 || cfg >= conv_num_cfgs()) return cfg == CONV_CFG_DIRECT ? "direct_c8" : "?";
     const CfgDesc &c = kCfgs[cfg];
+    if (c.id >= 54) { snprintf(names[cfg], sizeof names[cfg], "f%sc%d_s%d", c.tp == 12 ? "10x19" : "5x19", c.wc * c.tc * 16, c.ns); return names[cfg]; }
     snprintf(names[cfg], sizeof names[cfg], "%s%dc%d_s%d_k%d%s%d", c.halo ? (c.id >= 40 ? "f" : "h") : "p", c.wp * c.tp * 16, c.wc * c.tc * 16, c.ns, c.bk, c.nl ? "_L" : "_w", c.nl ? c.nl : c.wp * c.wc);
     return names[cfg];
 }
@@ -317,7 +321,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
         CONV_CFGS(X) CONV_CFGS_B(X)
 #undef X
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_conv_halo13(a, id, s);
-        CONV_CFGS_HALO(X)
+        CONV_CFGS_HALO(X) CONV_CFGS_HALO_R(X)
 #undef X
     default: return hipErrorInvalidValue;
     }

@@ -2,6 +2,7 @@
 // configurations) and conv_halo13.hip (halo-staged 3x3 configurations) so the two sets of instantiations compile in parallel.
 #pragma once
 #include "kernels.h"
+#include "halo_perm_tables.h"
 #include <type_traits>
 #include <utility>
 
@@ -104,41 +105,35 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { st
 // Bank conflicts: with 160-byte records a ds_read_b128 is conflict-free iff the halo indices y * 15 + x of lanes {0-3, 12-15}
 // and of lanes {4-11} of a 16-lane MFMA column group are distinct mod 8; kHaloPerm13 (tools/gen/halo_perm.py) assigns the
 // block's pixels to MFMA columns accordingly (raster order would conflict two-way in every group).
-// lane -> pixel assignment for a 13x13 block, generated by tools/gen/halo_perm.py (worst conflict degree 2, one group)
-constexpr unsigned short kHaloPerm13[176] = {
-    0x0000, 0x0101, 0x0202, 0x0303, 0x0808, 0x0909, 0x0a0a, 0x0b0b, 0x0c0c, 0x1313, 0x1414, 0x0d0d, 0x0404, 0x0505, 0x0606, 0x0707,
-    0x0e0e, 0x0f0f, 0x1010, 0x1111, 0x1616, 0x1717, 0x1818, 0x1919, 0x2020, 0x2727, 0x2222, 0x1b1b, 0x1212, 0x2121, 0x1a1a, 0x1515,
-    0x1c1c, 0x1d1d, 0x1e1e, 0x1f1f, 0x2424, 0x2525, 0x2626, 0x2d2d, 0x3434, 0x3535, 0x3030, 0x2929, 0x2e2e, 0x2f2f, 0x2828, 0x2323,
-    0x2a2a, 0x2b2b, 0x2c2c, 0x3b3b, 0x3232, 0x3333, 0x3a3a, 0x4141, 0x4242, 0x4343, 0x3e3e, 0x3737, 0x3c3c, 0x3d3d, 0x3636, 0x3131,
-    0x3838, 0x3939, 0x4848, 0x4949, 0x4040, 0x4747, 0x4e4e, 0x4f4f, 0x5050, 0x5151, 0x4c4c, 0x4545, 0x4a4a, 0x4b4b, 0x4444, 0x3f3f,
-    0x4646, 0x5555, 0x5656, 0x5757, 0x5454, 0x5b5b, 0x5c5c, 0x5d5d, 0x5e5e, 0x5f5f, 0x5a5a, 0x5353, 0x5858, 0x5959, 0x5252, 0x4d4d,
-    0x6262, 0x6363, 0x6464, 0x6565, 0x6868, 0x6969, 0x6a6a, 0x6b6b, 0x6c6c, 0x6d6d, 0x6e6e, 0x6f6f, 0x6666, 0x6767, 0x6060, 0x6161,
-    0x7070, 0x7171, 0x7272, 0x7373, 0x7676, 0x7777, 0x7878, 0x7979, 0x7a7a, 0x8989, 0x8282, 0x7d7d, 0x7474, 0x7b7b, 0x7c7c, 0x7575,
-    0x7e7e, 0x7f7f, 0x8080, 0x8181, 0x8484, 0x8585, 0x8686, 0x8787, 0x9696, 0x9797, 0x9090, 0x8b8b, 0x8888, 0x8f8f, 0x8a8a, 0x8383,
-    0x8c8c, 0x8d8d, 0x8e8e, 0x9595, 0x9292, 0x9393, 0x9494, 0xa3a3, 0xa4a4, 0xa5a5, 0x9e9e, 0x9999, 0x9c9c, 0x9d9d, 0x9898, 0x9191,
-    0x9a9a, 0x9b9b, 0xa2a2, 0xa8a8, 0xa0a0, 0xa1a1, 0xab02, 0xac03, 0xad04, 0xae05, 0xaf06, 0xa7a7, 0xa904, 0xaa05, 0xa6a6, 0x9f9f,
-};
-// The same table as a lane reads it: 32 bytes per l15 = two 16-byte loads issued with the kernel's first instructions (bytes 0..10: the
-// pixel whose window sub-tile j's lane reads; bytes 16..26: the row of the output tile it writes).  (Eleven byte loads per table
+// lane -> pixel assignment tables: generated, halo_perm_tables.h (13 x 13: worst conflict degree 2, one group; 10 x 19 and 5 x 19: none)
+// Round 5: the block is BH rows x BW columns (template parameters, 13 x 13 by default) -- 10 x 19 and 5 x 19 blocks tile the 608 x 608
+// network's 76 / 38 / 19 grids exactly and fill 256 CUs at 8 images per GPU (BASELINE config 4's share), where 13 x 13 blocks are ragged.
+// The same table as a lane reads it: 32 bytes per l15 = two 16-byte loads issued with the kernel's first instructions (bytes 0..TP-1: the
+// pixel whose window sub-tile j's lane reads; bytes 16..16+TP-1: the row of the output tile it writes).  (Eleven byte loads per table
 // sat behind the prologue's LDS-DMA in the in-order vmcnt queue: their first use waited for the whole prologue to land.)
 struct HaloPermPk { unsigned w[16][8]; };
-constexpr HaloPermPk make_halo_perm_pk()
+template <int N> constexpr HaloPermPk make_halo_perm_pk(const unsigned short (&tab)[N])
 {
     HaloPermPk t{};
     for (int l = 0; l < 16; ++l)
-        for (int j = 0; j < 11; ++j) {
-            const unsigned v = kHaloPerm13[j * 16 + l];
+        for (int j = 0; j < N / 16; ++j) {
+            const unsigned v = tab[j * 16 + l];
             t.w[l][j / 4] |= (v & 0xffu) << (8 * (j % 4));
             t.w[l][4 + j / 4] |= (v >> 8) << (8 * (j % 4));
         }
     return t;
 }
-__device__ const HaloPermPk kHaloPermPk = make_halo_perm_pk();
-constexpr int HALO_B = 13;                         // block edge (output pixels)
-constexpr int HALO_P = HALO_B + 2;                 // halo pitch and height (input pixels)
+__device__ const HaloPermPk kHaloPermPk = make_halo_perm_pk(kHaloPerm13);
+__device__ const HaloPermPk kHaloPermPk10x19 = make_halo_perm_pk(kHaloPerm10x19);
+__device__ const HaloPermPk kHaloPermPk5x19 = make_halo_perm_pk(kHaloPerm5x19);
+constexpr int HALO_B = 13;                         // default block edge (output pixels)
 constexpr int HALO_APIX = 160;                     // bytes of one halo pixel record in LDS
-constexpr int HALO_APIECES = (HALO_P * HALO_P * (HALO_APIX / 16) + 63) / 64;   // 1-KiB LDS-DMA pieces of one halo tile: 36
+constexpr int halo_apieces(int bh, int bw) { return ((bh + 2) * (bw + 2) * (HALO_APIX / 16) + 63) / 64; }      // 1-KiB LDS-DMA pieces of one halo tile: 36 for 13 x 13
+constexpr int HALO_APIECES = halo_apieces(HALO_B, HALO_B);
 constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
+// row / bw for row < 256 as a multiply and a shift (the epilogue's piece loop), checked exhaustively at compile time
+constexpr unsigned halo_div_mul(int bw) { return (65536u + bw - 1) / bw; }
+constexpr bool halo_div_ok(int bw) { for (unsigned r = 0; r < 256; ++r) if (((r * halo_div_mul(bw)) >> 16) != r / bw) return false; return true; }
 
 // FREE (halo form only): free-running waves.  Wave w fetches exactly the filter rows it multiplies itself (its TC * 16 channels:
 // LB = TC * 2 pieces per K-step into a private slice of the two filter stages), so inside a channel chunk nothing but the wave's
@@ -168,7 +163,7 @@ constexpr int HALO_ACT_BYTES = HALO_APIECES * 1024;
 // into block 1 (blocks a.out_blk elements apart) -- by an epilogue of its own that stages the tile in LDS as fp32, half its channels at a time,
 // and folds the shortcut; the K loop is the ordinary fp16 one, run over the 3 x Cin 'channels' hi | lo | hi of the input against filter rows
 // W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -199,8 +194,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     constexpr int L = LA + LB;
     constexpr int BPL = LA * NW * RG, BCL = LB * NW * RG;    // rows of the LDS images
     constexpr int STAGE_BYTES = (BPL + BCL) * RB;
-    static_assert(!HALO || (WP == 1 && TP == 11 && BK == 64 && UNI && (NS == 2 || (FREE && NS <= 4))), "halo form: one 13x13 block per workgroup; more than two filter stages in the free-running form only");
-    constexpr int HB = HALO_B, HP = HALO_P, APIX = HALO_APIX, APIECES = HALO_APIECES, ACT_BYTES = HALO_ACT_BYTES;
+    static_assert(!HALO || (WP == 1 && TP == (BH * BW + 15) / 16 && TP <= 16 && BK == 64 && UNI && (NS == 2 || (FREE && NS <= 4))), "halo form: one BH x BW block per workgroup; more than two filter stages in the free-running form only");
+    static_assert((BH == 13 && BW == 13) || (BH == 10 && BW == 19) || (BH == 5 && BW == 19), "block shapes with a generated permutation table");
+    static_assert(halo_div_ok(BW) && BH * BW <= 256, "row / BW by multiply-high");
+    constexpr int HBH = BH, HBW = BW, HPW = BW + 2, HPH = BH + 2, APIX = HALO_APIX, APIECES = halo_apieces(BH, BW), ACT_BYTES = APIECES * 1024;
     constexpr int LAH = HALO ? (APIECES + NW - 1) / NW : 1;    // halo pieces per loading wave (one per tap, taps 0..LAH-1)
     constexpr int FSTAGE = BCL * RB;                            // halo form: bytes of one filter stage
     static_assert(!HALO || LAH <= 9, "a halo tile is fetched during the nine taps of the previous chunk");
@@ -216,7 +213,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // halo form: this lane's slice of the pixel permutation, requested before anything else (it is independent of the arguments)
     u32x4_t perm_rd = {0, 0, 0, 0}, perm_wr = {0, 0, 0, 0};
     if constexpr (HALO) {
-        const u32x4_t *pk = (const u32x4_t *)kHaloPermPk.w[lane & 15];
+        const u32x4_t *pk = (const u32x4_t *)(BH == 10 ? kHaloPermPk10x19.w[lane & 15] : BH == 5 ? kHaloPermPk5x19.w[lane & 15] : kHaloPermPk.w[lane & 15]);
         perm_rd = pk[0]; perm_wr = pk[1];
     }
     // the arguments the way to the first LDS-DMA needs, as ONE burst of scalar loads (left alone the compiler fetches each field
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     const int tilesC = (a.Cout + BC - 1) / BC;
     // (halo form: a size that is not a multiple of 13 gets ragged blocks on its bottom / right edge -- their columns past the image read
     //  zeros from the halo tile, as padding does, and are never stored)
-    const int hbr = HALO ? (a.H + HB - 1) / HB : 0, hbc = HALO ? (a.W + HB - 1) / HB : 0;      // block rows / columns per image
+    const int hbr = HALO ? (a.H + HBH - 1) / HBH : 0, hbc = HALO ? (a.W + HBW - 1) / HBW : 0;      // block rows / columns per image
     const int tilesP = HALO ? a.N * hbr * hbc : (M + BP - 1) / BP;
     const int per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -277,7 +274,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // ~130 instructions; tiled form: ~55 per row group) then runs while they are in flight.  Order in the vmcnt queue: filters of step 0,
     // activations of step 0, later stages: the counted waits of the K loop only rely on whole K-steps retiring in order.
     if (is_loader && 0 < a.Kpad / BKE) {
-        char *const f0 = smem + (HALO ? 2 * HALO_ACT_BYTES : BPL * RB);
+        char *const f0 = smem + (HALO ? 2 * ACT_BYTES : BPL * RB);
 #pragma unroll
         for (int i = 0; i < LB; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(f0 + (FREE ? wid * LB + i : wid + i * NW) * 1024), 16, woff[i], 0, 0, 0);
@@ -292,9 +289,9 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         for (int i = 0; i < LAH; ++i) {
             const int g = (wid + i * NW) * 64 + lane;
             const int pix = g / (APIX / 16), c16 = g - pix * (APIX / 16);
-            const int hy = pix / HP, hx = pix - hy * HP;
-            const int iy = by * HB + hy - 1, ix = bx * HB + hx - 1;
-            const bool ok = pix < HP * HP && c16 < 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int hy = pix / HPW, hx = pix - hy * HPW;
+            const int iy = by * HBH + hy - 1, ix = bx * HBW + hx - 1;
+            const bool ok = pix < HPH * HPW && c16 < 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             aoff[i] = ok ? (unsigned)(((bn * a.H + iy) * a.W + ix) * a.in_stride * EB + c16 * 16) : OOB_OFFSET;
         }
     }
@@ -462,8 +459,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int p = (int)((perm_rd[j / 4] >> (8 * (j % 4))) & 0xffu);
-            const int y = p / HB, x = p - y * HB;
-            abase[j] = (y * HP + x) * APIX + lq * 16;
+            const int y = p / HBW, x = p - y * HBW;
+            abase[j] = (y * HPW + x) * APIX + lq * 16;
         }
     }
     int cur = 0, nxt = D % NS;                 // stage being multiplied / stage being filled
@@ -602,7 +599,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(fill_a + (wid + TAP * NW) * 1024), 16, aoff[TAP], next_chunk * RB, 0, HALO_LOAD_AUX);
         }
         __builtin_amdgcn_s_setprio(2);
-        mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HP + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
+        mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HPW + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
         __builtin_amdgcn_s_setprio(0);
     };
     // free-running halo form: one K-step of ONE wave (see the template comment).  Issue order inside a step: the wave's halo piece
@@ -652,7 +649,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         }
         f_ops2 = f_ops1; f_ops1 = ops_now;
         __builtin_amdgcn_s_setprio(2);
-        mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HP + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
+        mma_phase([&](int j) { return sb_a + abase[j] + ((TAP / 3) * HPW + TAP % 3) * APIX; }, [&](int i) { return sb_f + offw + i * 16 * RB; }, 0, 64);
         __builtin_amdgcn_s_setprio(0);
         if (DIAG) { if (!a.dbg_light) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); t_mma += stamp() - s2; }
     };
@@ -700,7 +697,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // offset is 32-bit (pixel index relative to the tile origin x pixel stride, one 24-bit multiply) and a row or channel that is not
     // stored gets an out-of-range offset (loads return zero, stores are dropped) -- no 64-bit address arithmetic, no exec-mask
     // branches.  The epilogue is VALU-issue-bound (two waves per SIMD, ~4 cycles per instruction each): instruction count is its cost.
-    const size_t m0 = HALO ? ((size_t)(bn * a.H + by * HB) * a.W + bx * HB) : (size_t)pt * BP;      // tile origin (flat pixel index)
+    const size_t m0 = HALO ? ((size_t)(bn * a.H + by * HBH) * a.W + bx * HBW) : (size_t)pt * BP;      // tile origin (flat pixel index)
     const int rows_left = HALO ? BP : (int)((size_t)M - m0 < (size_t)BP ? (size_t)M - m0 : (size_t)BP);    // tiled form: rows of the tile inside the tensor
     // descriptor based at `p` (a wave-uniform address; the read-first-lane pins it to SGPRs, otherwise every access is wrapped in a
     // waterfall loop)
@@ -712,14 +709,13 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     // byte offset (from the tile origin, channel tile ct) of 16-byte piece c of the tile -- row-major, `cpr` pieces of `cpp` channels
     // per row, pixel stride `sb` bytes -- or OOB_OFFSET when the piece is not stored; also returns the piece's row and position
     // halo form: rows / columns of this block inside the image (13 unless the block is a ragged one on the bottom / right edge)
-    const unsigned ylim = HALO ? (unsigned)(a.H - by * HB < HB ? a.H - by * HB : HB) : 0u, xlim = HALO ? (unsigned)(a.W - bx * HB < HB ? a.W - bx * HB : HB) : 0u;
+    const unsigned ylim = HALO ? (unsigned)(a.H - by * HBH < HBH ? a.H - by * HBH : HBH) : 0u, xlim = HALO ? (unsigned)(a.W - bx * HBW < HBW ? a.W - bx * HBW : HBW) : 0u;
     auto piece_off = [&](int c, int cpr, int cpp, unsigned sb, int &row, int &cc) -> unsigned {
         row = c / cpr; cc = c - row * cpr;
         unsigned rel; bool ok;
         if constexpr (HALO) {
-            static_assert(HB == 13 && BP < 350, "row / 13 as (row * 79) >> 10");
-            const unsigned y = __umul24((unsigned)row, 79u) >> 10, x = (unsigned)row - __umul24(y, 13u);
-            rel = __umul24(y, (unsigned)a.W) + x; ok = y < ylim && x < xlim;       // (y < 13 is row < 169)
+            const unsigned y = __umul24((unsigned)row, halo_div_mul(HBW)) >> 16, x = (unsigned)row - __umul24(y, (unsigned)HBW);       // row / BW (row < 256)
+            rel = __umul24(y, (unsigned)a.W) + x; ok = y < ylim && x < xlim;       // (y < BH is row < BH * BW)
         }
         else { rel = (unsigned)row; ok = row < rows_left; }
         ok = ok && ct * BC + cc * cpp < a.Cout;
@@ -1159,7 +1155,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
 }
 
 // dynamic LDS of one instantiation: NS staging buffers, re-used by the epilogue's padded output tile
-template <int WP, int WC, int TP, int TC, int NS, int BK, int NL = 0, bool HALO = false>
+template <int WP, int WC, int TP, int TC, int NS, int BK, int NL = 0, bool HALO = false, int BH = HALO_B, int BW = HALO_B>
 constexpr size_t conv_lds_bytes()
 {
     constexpr int NW = NL > 0 ? NL : WP * WC, BP = WP * TP * 16, BC = WC * TC * 16;
@@ -1167,6 +1163,6 @@ constexpr size_t conv_lds_bytes()
     constexpr int LA = ((BP + RG - 1) / RG + NW - 1) / NW, LB = ((BC + RG - 1) / RG + NW - 1) / NW;
     constexpr size_t stage = (size_t)(LA + LB) * NW * RG * (BK * 2);
     constexpr bool tail = WP == 1 && WC == 8 && (BC == 256 || BC == 128); // TAIL_OK shapes also stage the tail's [BP][BC/2] tile
-    constexpr size_t lds0 = HALO ? (size_t)2 * HALO_ACT_BYTES + (size_t)NS * LB * NW * RG * (BK * 2) : (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16) + (tail ? (size_t)BP * (BC + 16) : 0);
+    constexpr size_t lds0 = HALO ? (size_t)2 * halo_apieces(BH, BW) * 1024 + (size_t)NS * LB * NW * RG * (BK * 2) : (size_t)NS * stage, ldso = (size_t)BP * (BC * 2 + 16) + (tail ? (size_t)BP * (BC + 16) : 0);
     return lds0 > ldso ? lds0 : ldso;
 }

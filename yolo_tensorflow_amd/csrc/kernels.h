@@ -112,12 +112,13 @@ inline void conv_finalize(ConvArgs &a)
     conv_magic((uint32_t)(a.Ho * a.Wo), a.howo_mul, a.howo_shift);
     conv_magic((uint32_t)a.Wo, a.wo_mul, a.wo_shift);
 }
-// launcher side of the tile decode: BC = output channels per workgroup, hb = block edge of the halo form (0: tiled form)
-inline ConvArgs conv_tile_magic(const ConvArgs &a0, int BC, int hb)
+// launcher side of the tile decode: BC = output channels per workgroup, bh x bw = block (rows x columns) of the halo form (0: tiled form)
+inline ConvArgs conv_tile_magic(const ConvArgs &a0, int BC, int bh, int bw = 0)
 {
     ConvArgs a = a0;
+    if (bw == 0) bw = bh;
     conv_magic((uint32_t)((a.Cout + BC - 1) / BC), a.tc_mul, a.tc_shift);
-    if (hb > 0) { const int br = (a.H + hb - 1) / hb, bc = (a.W + hb - 1) / hb; conv_magic((uint32_t)(br * bc), a.bpi_mul, a.bpi_shift); conv_magic((uint32_t)bc, a.bpr_mul, a.bpr_shift); }      // (ragged edge blocks included)
+    if (bh > 0) { const int br = (a.H + bh - 1) / bh, bc = (a.W + bw - 1) / bw; conv_magic((uint32_t)(br * bc), a.bpi_mul, a.bpi_shift); conv_magic((uint32_t)bc, a.bpr_mul, a.bpr_shift); }      // (ragged edge blocks included)
     return a;
 }
 
@@ -132,7 +133,8 @@ const char *conv_cfg_name(int cfg);
 int conv_pick_cfg(const ConvArgs &a);
 hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s);
 // halo-staged 3x3 / stride 1 form (conv_halo13.hip): bf16 or fp8 operands, spatial size a multiple of 13, whole 128-byte channel chunks
-bool conv_halo13_ok(const ConvArgs &a);
+bool conv_halo13_ok(const ConvArgs &a);                  // the 13 x 13-block halo forms (tile configurations 36..43)
+bool conv_halo_cfg_ok(const ConvArgs &a, int cfg);       // ... and the block shape of halo configuration `cfg` (round 5: 10 x 19 and 5 x 19 blocks, 54..56)
 bool conv_cfg_is_halo(int cfg);
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant = 0);   // 0: eight waves of 176 x 32 (the shipped shape), 1: four waves of 176 x 64      // stamped free-running 176x256 build (tools only)

@@ -52,7 +52,7 @@ static int op_conv2d_split(const float *x, int n, int h, int w, int cin, const f
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, DT_F16); a.act = act; a.zeros = d_z;
     conv_finalize(a);
     int cfg = tile_cfg >= 0 ? tile_cfg : 6;
-    if (!conv_cfg_split_ok(cfg) || (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
+    if (!conv_cfg_split_ok(cfg) || (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
     // the shortcut: fused into the conv's epilogue, or (YOLO_SPLIT_UNFUSED, the parity tests' A/B) as the separate launch a keep_layers plan makes
     void *d_r = nullptr;
     if (residual) {
@@ -111,7 +111,7 @@ int yolo_op_conv2d(const float *x, int n, int h, int w, int cin, const float *w_
     a.res = d_r; a.res_stride = cstride; a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, dt); a.act = act; a.zeros = d_z;
     conv_finalize(a);
-    if (conv_cfg_is_halo(tile_cfg) && (f32 || !conv_halo13_ok(a))) { g_op_err = "conv2d: tile config not applicable to this shape (halo-staged form: 3x3, stride 1, size a multiple of 13, whole channel chunks)"; return YOLO_ERR_UNSUPPORTED; }
+    if (conv_cfg_is_halo(tile_cfg) && (f32 || !conv_halo_cfg_ok(a, tile_cfg))) { g_op_err = "conv2d: tile config not applicable to this shape (halo-staged form: 3x3, stride 1, size a multiple of 13, whole channel chunks)"; return YOLO_ERR_UNSUPPORTED; }
     hipError_t e;
     if (dt != DT_F32 && dt != DT_F16 && getenv("YOLO_CONV_DIAG") && a.Cin_pad % (dt == DT_FP8 ? 128 : 64) == 0) {
         // developer diagnostic: phase cycle sums of the stamped p176c128_s2 build (YOLO_CONV_DIAG=free: of the free-running halo form

@@ -126,19 +126,19 @@ int run_layer(yolo_ctx *c, int i, int n)
         }
         if (a.split) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_split_ok(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
-            if (conv_cfg_is_halo(cfg) && (!conv_halo13_ok(a) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
+            if (conv_cfg_is_halo(cfg) && (!conv_halo_cfg_ok(a, cfg) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
         else if (c->dtype == YOLO_FP32) { HIPCK(c, launch_conv_f32(a, s)); }
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
-            if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
+            if (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
             if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_fp8(a, cfg, s));
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
-            if (conv_cfg_is_halo(cfg) && !conv_halo13_ok(a)) cfg = conv_pick_cfg(a);
+            if (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg)) cfg = conv_pick_cfg(a);
             if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
@@ -529,7 +529,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     auto valid = [&](const Layer &L, int cfg) {
         if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
-        if (a.split) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo13_ok(a) && a.out_dt != DT_F32));
+        if (a.split) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo_cfg_ok(a, cfg) && a.out_dt != DT_F32));
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
@@ -597,7 +597,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
                 bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8) && c->layers[L.tail_layer].in_dt == L.in_dt && valid(L, cfg);      // (valid: e.g. a shape the e4m3 table does not instantiate)
-                if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo13_ok(a); }
+                if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo_cfg_ok(a, cfg); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
             if (!any) continue;
@@ -647,7 +647,7 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
         if (tail && conv_cfg_is_halo(v)) {
             ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
-            if (!conv_halo13_ok(a)) return fail(c, YOLO_ERR_INVALID, "layer %zu: the halo-staged tile config %d does not apply to this layer, so it cannot carry the fused 1x1 tail", i, v);
+            if (!conv_halo_cfg_ok(a, v)) return fail(c, YOLO_ERR_INVALID, "layer %zu: the halo-staged tile config %d does not apply to this layer, so it cannot carry the fused 1x1 tail", i, v);
         }
         c->layers[i].tile_cfg = v; c->layers[i].tail_on = tail;
     }
