@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
                 o = uint4{ov[0], ov[1], ov[2], ov[3]};
             }
             if (oy < a.H && ox < a.W)
-                out_store16((bf16_t *)a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8, o.x, o.y, o.z, o.w);
+                out_store16_at(a.out, (unsigned)((((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8) * 2), o.x, o.y, o.z, o.w);       // (conv_halo_ok: the tensor is below 2 GiB)
         }
         // the next tile writes `lo` / `lres` only after its own pre-store barrier / its fetch: `lres` is re-filled at the
         // start of the next tile, so every thread must be past the reads above first
@@ -578,7 +578,7 @@ bool conv_halo_ok(const HaloArgs &a)
 {
     // 32-bit buffer offsets below 0x80000000 (the out-of-range sentinel): input and shortcut windows must stay under 2 GiB
     const double px = (double)a.N * a.H * a.W;
-    if (px * a.in_stride * 2.0 >= 2147483648.0 || (a.res && px * a.res_stride * 2.0 >= 2147483648.0)) return false;
+    if (px * a.in_stride * 2.0 >= 2147483648.0 || (a.res && px * a.res_stride * 2.0 >= 2147483648.0) || px * a.out_stride * 2.0 >= 2147483648.0) return false;
     return (a.dt == DT_BF16 || a.dt == DT_F16) && a.Cin == 32 && a.Cout == 64 && a.Kpad >= 288 && (a.in_stride % 8) == 0 && a.in_stride >= 32 && (a.out_stride % 8) == 0 &&
            a.out_stride >= 64 && (!a.res || ((a.res_stride % 8) == 0 && a.res_stride >= 64));
 }

@@ -28,7 +28,7 @@ template <> struct Elt<bf16_t> {
         uint4 u;
         u.x = cvt(v[0]) | (cvt(v[1]) << 16); u.y = cvt(v[2]) | (cvt(v[3]) << 16);
         u.z = cvt(v[4]) | (cvt(v[5]) << 16); u.w = cvt(v[6]) | (cvt(v[7]) << 16);
-        out_store16(p, u.x, u.y, u.z, u.w);             // (the conv kernels' output-store policy: kernels.h OUT_STORE_AUX)
+        *(uint4 *)p = u;
     }
     static __device__ __forceinline__ float load1(const bf16_t *p) { return __builtin_bit_cast(float, (uint32_t)(*p) << 16); }
     static __device__ __forceinline__ void store1(bf16_t *p, float f) { *p = (bf16_t)cvt(f); }
@@ -50,7 +50,7 @@ template <> struct Elt<f16_t> {       // IEEE binary16: decode exact, encode rou
     }
     static __device__ __forceinline__ void store8(f16_t *p, const float *v)
     {
-        out_store16(p, pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7]));
+        *(uint4 *)p = uint4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
     }
     static __device__ __forceinline__ float load1(const f16_t *p) { return (float)__builtin_bit_cast(_Float16, p->b); }
     static __device__ __forceinline__ void store1(f16_t *p, float f) { p->b = (uint16_t)(pk(f, 0.f) & 0xffffu); }

@@ -17,23 +17,16 @@
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-// the same policy for a 16-byte store through a plain pointer (kernels that do not hold a buffer descriptor for their output)
+// the same policy for a 16-byte store of a kernel that holds no descriptor for its output: a buffer store based at the tensor (`base`
+// wave-uniform, byte offset below 2 GiB).  (NOT inline asm: a `global_store ... sc1` written as asm is a vector-memory operation the
+// compiler's vmcnt bookkeeping does not see -- its counted waits for the loads around it then wait for one operation too few.  Round 5: the
+// fp32 head path written that way returned garbage at batch 32 and passed every small test.)
 typedef unsigned out_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void out_store16(void *p, unsigned x, unsigned y, unsigned z, unsigned w)
+__device__ __forceinline__ void out_store16_at(const void *base, unsigned byte_off, unsigned x, unsigned y, unsigned z, unsigned w)
 {
-    const out_u32x4 v = {x, y, z, w};
-#if !defined(__HIP_DEVICE_COMPILE__)
-    *(out_u32x4 *)p = v;                   // (host pass: never executed)
-#elif OUT_STORE_AUX == 16
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#elif OUT_STORE_AUX == 17
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-#elif OUT_STORE_AUX == 2
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-#elif OUT_STORE_AUX == 18
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-#else
-    *(out_u32x4 *)p = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x80000000u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(out_u32x4{x, y, z, w}, r, byte_off, 0, OUT_STORE_AUX);
 #endif
 }
 
