@@ -1102,9 +1102,10 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             }
         }
     } else if (is_consumer && !HALO) {
-        // fp32 output (detection heads, Cout = 255): 4 consecutive channels per lane, 16-B stores (write-through like every output while the
-        // tensor is within a buffer descriptor's 2 GiB; plain beyond)
-        const bool head_small = (size_t)M * a.out_stride * 4 < 0x80000000ull;
+        // fp32 output (detection heads, Cout = 255): 4 consecutive channels per lane, 16-B stores.  PLAIN stores, unlike every other output
+        // (OUT_STORE_AUX): a lane writes 16 bytes of its own pixel's 1 KB row, 64 different rows per instruction -- write-through sends each
+        // piece to memory alone, while a plain store lets L2 assemble whole lines first (round 5, same tile: 33 -> 69 us on the 52 x 52 head,
+        // 17 -> 26 us on the 26 x 26 one with sc1)
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int ch = ct * BC + (wci * TC + i) * 16 + lq * 4;
@@ -1136,10 +1137,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 }
                 float *o = (float *)a.out + (size_t)m * a.out_stride + ch;
                 if (oq >= 0) a.obj_out[(size_t)m * a.obj_na + oan] = oq == 0 ? v[0] : oq == 1 ? v[1] : oq == 2 ? v[2] : v[3];
-                if (ch + 3 < a.Cout) {
-                    if (head_small) out_store16_at(a.out, (unsigned)(((size_t)m * a.out_stride + ch) * 4), __builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
-                    else *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
-                }
+                if (ch + 3 < a.Cout) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
                 else
                     for (int q = 0; q < 4; ++q) if (ch + q < a.Cout) o[q] = v[q];
             }
