@@ -174,7 +174,7 @@ def test_fp16x2_refuses_what_it_does_not_serve(hiplib):
 
 # ---- mixed plans (round 5): pairs on some tensors, plain fp16 on the rest (cfg keys yolo_pair / yolo_pair_input) ----
 @pytest.mark.parametrize("want_name,want", [("first twelve layers", set(range(-1, 12))), ("26 x 26 stage to the first FPN block", set(range(37, 87))), ("none", set())])
-def test_mixed16_network_vs_emulation_every_layer(hiplib, want_name, want):
+def test_mixed16_network_vs_emulation_every_layer(hiplib, want_name, want, tmp_path):
     """A split-fp16 network in which only some tensors are pairs: every layer against the oracle's emulation of exactly that plan
     (oracle.forward_f16x2(pair=...)); tensors that are pairs all the way up agree like the all-pairs network (2e-5 of scale), anything
     downstream of a plain fp16 tensor like the fp16 network (4e-3: rounding flips of the 11-bit type compound); the production plan --
@@ -215,7 +215,13 @@ def test_mixed16_network_vs_emulation_every_layer(hiplib, want_name, want):
     eng.set_weights(flat)
     det = eng.forward(img)
     assert np.array_equal(det, det_unfused)
+    # the plan travels in the export artifact (it is part of the cfg text)
+    path = str(tmp_path / "mixed16.yolohip")
+    eng.export(path)
     eng.close()
+    e2 = hiplib.Engine.from_file(path, max_batch=2)
+    assert np.array_equal(e2.forward(img), det)
+    e2.close()
     if not want:
         e16 = hiplib.Engine(txt0, max_batch=2, dtype=hiplib.FP16)
         e16.set_weights(flat)
