@@ -170,6 +170,10 @@ def test_fp16x2_batch32_416_log_statistics_and_autotune(hiplib):
 def test_fp16x2_refuses_what_it_does_not_serve(hiplib):
     with pytest.raises(hiplib.YoloError, match="split-fp16"):
         hiplib.Engine(IO.cfg_text("yolov1"), dtype=hiplib.FP16X2)
+    # a max_batch whose whole-batch activation window passes the conv kernels' 32-bit offsets is refused at yolo_create with the
+    # number that does fit (a split tensor is 3 x as wide: 416 x 416 stops at 64 images), not at the first forward with a bare 'invalid value'
+    with pytest.raises(hiplib.YoloError, match=r"at most 6\d images"):
+        hiplib.Engine(IO.cfg_text("yolov3"), max_batch=70, dtype=hiplib.FP16X2)
 
 
 # ---- mixed plans (round 5): pairs on some tensors, plain fp16 on the rest (cfg keys yolo_pair / yolo_pair_input) ----
