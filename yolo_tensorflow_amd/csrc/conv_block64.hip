@@ -13,10 +13,14 @@
 // 23 KB, 36 filter registers per wave), so TWO workgroups fit a CU (61 KB of LDS and <= 128 VGPRs each) and one's fetch / staging / stores
 // run under the other's MFMAs; the x tile is single-buffered (the co-resident workgroup is the latency cover) and stays valid to the end of
 // the block, which is what lets the shortcut come from LDS.
+// MEASURED (416 x 416 x 32, bf16, per-layer events): 130 us as first written, 118 us with the interior-block fast path below (addresses = per-lane
+// constants + one scalar soffset per block), against 108 us for conv_halo_c32_c64, the launch it replaces; the stem is no faster without its
+// 1x1 tail.  ~650-800 instructions per wave and block for 62 MFMAs, five barriers: instruction-issue-bound.  Hence OPT-IN (YOLO_RESBLOCK64=1).
 //
 //   waves    8 = 4 channel groups (16 output channels of the 3x3) x 2 pixel halves (sub-tiles 0-5 / 6-10 of the block's 11)
 //   stage 1  wave u takes halo-pixel sub-tiles 2u, 2u+1: two K-steps of (2 pixel fragments, 2 filter fragments from LDS, 4 MFMAs)
-//   stage 2  per tap 6 ds_read_b128 at precomputed addresses (the tap is an immediate offset) and 6 MFMAs, reads one tap ahead
+//   stage 2  per (tap, half of the wave's sub-tiles) 3 ds_read_b128 at precomputed addresses (the tap is an immediate offset) and 3 MFMAs; the
+//            fragments are not double-buffered: 128 registers per wave, the SIMD's other three waves cover the LDS latency
 //   epilogue bias, leaky, rounding -> LDS (over the dead mid tile) -> 16-byte pieces + the x piece of the same pixel from the x tile,
 //            rounded once more (as the separate shortcut kernel would) -> global; the next block's x tile is requested before the stores
 // LDS layouts: x tile 128-byte pixel rows, 16-byte slot XOR (pixel & 7) (applied to the SOURCE chunk of the lane-linear LDS-DMA):

@@ -1,5 +1,6 @@
 // Halo-staged instantiations of the implicit-GEMM conv kernel (conv_igemm_kernel.h, HALO = true): 3x3 / stride 1 / pad 1 layers
-// whose spatial size is a multiple of 13 -- every residual-block 3x3 conv of a 416x416 darknet-53 (104, 52, 26, 13).
+// whose spatial size is a multiple of 13 -- every residual-block 3x3 conv of a 416x416 darknet-53 (104, 52, 26, 13) --, or (round 5) tiles
+// into 10 x 19 blocks / 5 x 19 strips: the 76 / 38 / 19 grids of the 608x608 network (tile configurations 54..56).
 // Replaces the same reference chain as conv_igemm.hip (DN/convolutional_layer.c:445-485; slim.conv2d V3/yolo_v3.py:47-60).
 #include "conv_igemm_kernel.h"
 

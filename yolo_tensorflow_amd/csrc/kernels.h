@@ -3,7 +3,8 @@
 // Cache policy of the conv kernels' OUTPUT stores (aux operand of buffer_store on gfx950: 0 plain write-back, 2 nt, 16 sc1, 17 sc0 sc1).
 // Round 5: sc1 -- write-through to memory as the epilogue runs, instead of leaving up to 32 MB of dirty lines for the end-of-kernel L2
 // write-back, which is serial with the next launch.  Same-box A/B, YOLOv3-416 batch 32 bf16 (tools/probe/ab/ab_multi.sh, four interleaved
-// rounds): conv stack 2.578 -> 2.505 ms per forward, 12.01 -> 12.38 k img/s with sc1 on the tiled / halo conv's stores alone; nt: no change.
+// rounds): conv stack 2.495 -> 2.367 ms per forward, 12.44 -> 13.08 k img/s; sc0 sc1 the same, sc1 nt worse, nt alone no change.  Only for
+// COALESCED stores (whole 128-byte lines per lane group): the fp32 head path, 16 bytes per lane into 64 different rows, stays plain.
 #ifndef OUT_STORE_AUX
 #define OUT_STORE_AUX 16
 #endif
