@@ -155,3 +155,67 @@ def test_draw_detection_counterpart(tmp_path):
     out = draw.draw_detection(im, boxes, scores, cls, labels, thr=0.3, ratio=True)
     assert out.shape == im.shape and (im == 30).all()
     assert tuple(out[150, 60]) == want[3] and tuple(out[120, 450]) == want[7] and tuple(out[200, 100]) == (30, 30, 30)
+
+
+def test_real_batch_norm_vectors_fixture():
+    """tests/golden/yolov3_bn_real.npz / yolov2_bn_real.npz: the batch-norm vectors the reference itself printed (D2T/log.txt:224-949 and
+    :1-222 through DN/parser.c:1176-1228; tools/make_golden.py bn_real).  Shapes follow the topologies, the first numbers are the log's, and
+    the stand-in built from them keeps beta / gamma / variance exactly and is a valid weight stream."""
+    import numpy as np
+    from yolo_tensorflow_amd import darknet_io as IO
+    secs = IO.parse_cfg(IO.cfg_text("yolov3"))
+    real = IO.bn_real_vectors(secs)
+    convs = [s for s in secs[1:] if s["type"] == "convolutional"]
+    assert len(real) == len(convs) == 75 and sum(r is not None for r in real) == 72
+    for s, r in zip(convs, real):
+        assert (r is None) == (int(s.get("batch_normalize", 0)) == 0)
+        if r is not None:
+            assert all(r[k].shape == (int(s["filters"]),) for k in ("beta", "gamma", "mean", "var", "w_first"))
+    r0 = real[0]      # D2T/log.txt:225-231
+    np.testing.assert_allclose(r0["beta"][:3], [-4.31688, -0.757808, -2.1098], rtol=1e-6)
+    np.testing.assert_allclose(r0["gamma"][:3], [2.6224, 1.35365, 1.62867], rtol=1e-6)
+    np.testing.assert_allclose(r0["var"][:2], [0.0816501, 0.141673], rtol=1e-6)
+    assert min(r["var"].min() for r in real if r is not None) < 1e-12          # the file has dead channels
+    flat = IO.synth_weights(secs, seed=3, stats="real")
+    from oracle import yolo_ref as R
+    osecs = R.parse_cfg(IO.cfg_text("yolov3"))
+    params = R.unflatten_weights(flat, osecs)
+    bn = [p for p in params if "var" in p]
+    assert len(bn) == 72 and np.array_equal(bn[0]["beta"], r0["beta"]) and np.array_equal(bn[5]["gamma"], [r for r in real if r is not None][5]["gamma"])
+    v2 = IO.bn_real_vectors(IO.parse_cfg(IO.cfg_text("yolov2")))
+    assert len(v2) == 23 and sum(r is not None for r in v2) == 22 and abs(float(v2[0]["beta"][0]) + 11.1273) < 1e-4      # D2T/log.txt:2
+    with pytest.raises(ValueError):
+        IO.bn_real_vectors(IO.parse_cfg(IO.cfg_text("yolov3-tiny")))
+
+
+def test_pair_closure_and_cfg_keys():
+    """Mixed fp16 / split-fp16 plans (darknet_io.pair_closure / with_layer_pairs): the wish list is closed under 'a shortcut's operands and a
+    concatenation's inputs share one form', layers that move data inherit, heads are never pairs, and the cfg text carries the result."""
+    from yolo_tensorflow_amd import darknet_io as IO
+    txt = IO.cfg_text("yolov3"); secs = IO.parse_cfg(txt); L = secs[1:]
+    pair = IO.pair_closure(secs, set(range(-1, 12)))
+    assert [i for i, v in pair.items() if v] == list(range(-1, 12))                 # the first residual stages close on themselves
+    assert abs(IO.pair_flop_share(secs, pair) - 0.158) < 2e-3
+    # asking for one conv inside a residual stream pulls in the whole stream (every shortcut of the 52 x 52 stage), nothing outside it
+    p2 = IO.pair_closure(secs, {14})
+    stream = [i for i in range(12, 37) if L[i]["type"] == "shortcut"]
+    assert all(p2[i] for i in stream) and p2[12] and not p2[11] and not p2[13] and not p2[37]
+    for i, s in enumerate(L):
+        if s["type"] == "shortcut":
+            f = int(s["from"]); f = f if f >= 0 else i + f
+            assert p2[i] == p2[i - 1] == p2[f]
+        if s["type"] == "route" and "," in s["layers"]:
+            ins = [int(v) if int(v) >= 0 else i + int(v) for v in s["layers"].split(",")]
+            assert len({p2[j] for j in ins} | {p2[i]}) == 1
+        if s["type"] == "yolo":
+            assert not p2[i] and not p2[i - 1]
+    # everything: heads stay fp32
+    allp = IO.pair_closure(secs, set(range(-1, len(L))))
+    assert sum(allp.values()) == len(L) + 1 - 6
+    t2 = IO.with_layer_pairs(txt, pair)
+    assert t2.count("yolo_pair=0") == 75 - 9 and "yolo_pair_input" not in t2
+    s2 = IO.parse_cfg(t2)
+    assert [i for i, s in enumerate(s2[1:]) if s["type"] == "convolutional" and s.get("yolo_pair") != "0"] == [0, 1, 2, 3, 5, 6, 7, 9, 10]
+    t3 = IO.with_layer_pairs(txt, IO.pair_closure(secs, set()))
+    assert "yolo_pair_input=0" in t3 and t3.count("yolo_pair=0") == 75
+    assert IO.with_layer_pairs(t3, allp).count("yolo_pair") == 3                   # (idempotent: old keys are dropped; only the three heads say plain)
