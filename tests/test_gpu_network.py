@@ -550,3 +550,38 @@ def test_fused_first_residual_block_equals_the_separate_launches(hiplib, monkeyp
     assert np.isfinite(got).all() and np.array_equal(got, want)
     assert fused_bytes == plain_bytes        # (the counted tensors are the same size either way: what the block saves is the shortcut's re-read of x, which conv_bytes never counted)
     assert np.array_equal(alone[0], got[0])
+
+
+@pytest.mark.parametrize("dtype_name,batch,size,cfgs", [("bf16", 3, 416, (40, 36)), ("fp16", 1, 416, (40,)), ("bf16", 2, 608, (54,))])
+def test_head_as_the_tail_of_its_3x3_equals_the_separate_launch(hiplib, dtype_name, batch, size, cfgs):
+    """Round 5: darknet-53's 52 x 52 detection head (1x1, 256 -> 255, fp32, linear; cfg layer 105) computed in the epilogue of the 3x3 conv in
+    front of it (cfg layer 104, halo-staged 176 x 256 form) from the finished tile in LDS -- the plan code `40 + 10000` on layer 104 -- against
+    the plan that launches the head conv itself: decoded tensors, raw head tensors and detections bit for bit (same K order, fp32 accumulator
+    + bias, the objectness plane the lean decode reads included)."""
+    dtype = {"bf16": hiplib.BF16, "fp16": hiplib.FP16}[dtype_name]
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)            # (608: the 76 x 76 head behind the 10 x 19-block form, configuration 54)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=31)
+    img = np.random.default_rng(32).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=batch, dtype=dtype)
+    eng.set_weights(flat)
+    plain = eng.get_tile_configs().copy()
+    plain = np.where(plain >= 10000, plain - 10000, plain)
+    eng.set_tile_configs(plain)
+    want = eng.forward(img); want_raw = eng.head_raw(2, batch)
+    want_boxes = eng.detect(img, score_thr=0.5, iou_thr=0.5, max_out=20)
+    layer = [i for i, s in enumerate(secs[1:]) if s["type"] == "yolo"][2] - 2            # the 3x3 in front of the last head conv
+    assert int(secs[1 + layer]["filters"]) == 256 and int(secs[1 + layer]["size"]) == 3
+    for cfg in cfgs:
+        trial = plain.copy(); trial[layer] = 10000 + cfg
+        eng.set_tile_configs(trial)
+        got = eng.forward(img)
+        assert np.array_equal(got, want), cfg
+        assert np.array_equal(eng.head_raw(2, batch), want_raw), cfg
+        boxes = eng.detect(img, score_thr=0.5, iou_thr=0.5, max_out=20)              # the lean path: objectness plane written by the tail
+        for b in range(batch):
+            assert np.array_equal(boxes[b], want_boxes[b]), (cfg, b)
+    # a tile configuration that cannot host a head is refused
+    bad = plain.copy(); bad[layer] = 10000 + 32
+    with pytest.raises(hiplib.YoloError):
+        eng.set_tile_configs(bad)
+    eng.close()

@@ -235,11 +235,12 @@ static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X) C
 #undef XH
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
 bool conv_cfg_is_halo(int cfg) { return cfg >= 0 && cfg < conv_num_cfgs() && kCfgs[cfg].halo; }
-bool conv_cfg_tail_ok(int cfg, int cout, bool fp8)
+bool conv_cfg_tail_ok(int cfg, int cout, bool fp8, bool head)
 {
     if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
     const CfgDesc &c = kCfgs[cfg];
     const int bc = c.wc * c.tc * 16;
+    if (head) return !fp8 && c.halo && c.wp == 1 && c.wc == 8 && c.nl == 0 && bc == 256 && cout == 256;      // a head as the tail: the halo forms' two-channel-tile waves
     return c.wp == 1 && c.wc == 8 && (fp8 ? bc == 256 : c.nl == 0 && (bc == 256 || bc == 128)) && bc == cout;      // (as TAIL_OK in the kernel)
 }
 const char *conv_cfg_name(int cfg)

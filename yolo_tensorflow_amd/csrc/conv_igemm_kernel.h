@@ -894,7 +894,11 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         // (T2W = 2 in the halo forms, 1 in the tiled 8-wave shape, which has no registers for 64 of filter fragments).  A wave's filter
         // fragments (16 T2W rows x BC) are fetched here -- the accumulators are dead, the store loop below covers the latency
         constexpr int C2 = BC / 2, K2S = BC / 32, T2W = HALO ? 2 : 1, T2G = (C2 / (16 * T2W)) > 0 ? C2 / (16 * T2W) : 1, T2P = 8 / T2G > 0 ? 8 / T2G : 1;
-        const int t2g = wave_id % T2G, t2p = wave_id / T2G;
+        // (round 5) the tail may be a detection HEAD (a.tail_f32; halo forms with BC = 256 only): up to 256 filters, so every wave owns its own
+        // 32 of them for ALL pixel sub-tiles, and the result leaves as fp32 rows straight from the accumulators, as the stand-alone head does
+        constexpr bool HEAD_TAIL_OK = TAIL_OK && EB == 2 && HALO && BC == 256;
+        const bool head_tail = HEAD_TAIL_OK && a.tail_f32;
+        const int t2g = head_tail ? wave_id : wave_id % T2G, t2p = head_tail ? 0 : wave_id / T2G;
         bf16x8 fw2[TAIL_OK && EB == 2 ? T2W : 1][TAIL_OK && EB == 2 ? K2S : 1];
         auto load_fw2 = [&]() {
             if constexpr (TAIL_OK && EB == 2)
@@ -1000,6 +1004,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // pieces to COMPLETE -- five memory operations in flight per wave instead of all of them.  (The tail's write-back stays a
             // run-time branch: an LDS store does not touch vmcnt, and a third copy of the loop costs registers.)
             const bool tail_wb = TAIL_OK && EB == 2 && a.w2;
+            // a head riding as the tail is this conv's ONLY reader (planner): its own tensor is never stored (wave-uniform)
+            const bool skip_out = HEAD_TAIL_OK && a.tail_f32 && a.w2;
             auto store_tile = [&](auto resc) {
                 constexpr bool RES = decltype(resc)::value;
 #pragma unroll
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                         }
                         if (tail_wb) *(u32x4_t *)(smem + row * RS + cc * 16) = o;     // the tail consumes the summed tile
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, OUT_STORE_AUX);
+                    if (!skip_out) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, OUT_STORE_AUX);
                 }
             };
             if (res) store_tile(std::true_type{}); else store_tile(std::false_type{});
@@ -1041,14 +1047,36 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     f32x4 b2v[T2W];
 #pragma unroll
                     for (int t = 0; t < T2W; ++t) b2v[t] = *(const f32x4 *)(a.b2 + (t2g * T2W + t) * 16 + lq * 4);
+                    // head mode: raster row r = j * 16 + l15 of the block -> its pixel; this lane's four channels and whether one of them is a box's objectness logit
+                    const int hch = (t2g * T2W) * 16 + lq * 4;
                     auto finish = [&](const f32x4 &acc2, int j, int t) {
                         f32x4 v = acc2 + b2v[t];
+                        if constexpr (HEAD_TAIL_OK) if (head_tail) {
+                            // (exactly the stand-alone head's arithmetic: fp32 accumulator + bias, linear; same K order -> the same bits)
+                            const unsigned r = (unsigned)(j * 16 + l15), y = __umul24(r, halo_div_mul(BW)) >> 16, x = r - __umul24(y, (unsigned)BW);
+                            if (y < ylim && x < xlim) {
+                                const size_t m = m0 + (size_t)y * a.W + x;
+                                const int ch = hch + t * 16;
+                                float *o = (float *)a.out2 + m * a.out2_stride + ch;
+                                if (a.obj_out) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const int an = fast_div(ch + q, a.obj_mul, a.obj_shift);
+                                        if (ch + q - an * a.obj_attrs == 4 && ch + q < a.C2out) a.obj_out[m * a.obj_na + an] = v[q];
+                                    }
+                                }
+                                if (ch + 3 < a.C2out) *(float4 *)o = float4{v[0], v[1], v[2], v[3]};
+                                else
+                                    for (int q = 0; q < 4; ++q) if (ch + q < a.C2out) o[q] = v[q];
+                            }
+                            return;
+                        }
                         const f32x4 u = v * slope2;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = vmax_f32(v[q], u[q]);
                         *(uint2 *)(st2 + (j * 16 + l15) * RS2 + ((t2g * T2W + t) * 16 + lq * 4) * 2) = uint2{pack16x2<H16>(v[0], v[1]), pack16x2<H16>(v[2], v[3])};
                     };
-                    const int j0 = (TP * t2p) / T2P, j1 = (TP * (t2p + 1)) / T2P;       // this wave's pixel sub-tiles
+                    const int j0 = head_tail ? 0 : (TP * t2p) / T2P, j1 = head_tail ? TP : (TP * (t2p + 1)) / T2P;       // this wave's pixel sub-tiles
                     // Two sub-tiles at a time: 2 T2W independent accumulation chains, each K-ordered; the loop stays rolled so the fragment
                     // reads are not all hoisted.  (Reading the next pair's fragments under the MFMAs of the current one -- a second
                     // 64-register buffer -- measured slower in the stamped build, 5500 vs 4650 cycles.)
@@ -1093,6 +1121,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 if (DIAG) te6 = stamp();
                 constexpr int CPR2 = C2 / 8;
                 const __amdgpu_buffer_rsrc_t rs_out2 = tile_rsrc((char *)a.out2 + m0 * a.out2_stride * 2);
+                if (!head_tail)          // (a head left from the registers above)
 #pragma unroll
                 for (int it = 0; it < (BP * CPR2 + NT - 1) / NT; ++it) {
                     int row, cc;

@@ -85,6 +85,8 @@ struct ConvArgs {
     float *obj_out; int obj_attrs, obj_na; uint32_t obj_mul, obj_shift;
     unsigned long long *dbg;             // diagnostic builds only: per-wave phase cycle sums
     int dbg_light;                       // diagnostic builds only: 1 = stamp once around the K loop and nothing inside it (the in-kernel clock measurement)
+    int C2out;                                // ... its real filter count (255)
+    int tail_f32;                             // the fused tail is a detection HEAD: C2 = up to 256 filters, fp32 output [pixel][out2_stride] + bias, linear, objectness plane (obj_*)
     // division constants of the tile decode, filled by the launcher for its tile shape (conv_tile_magic): channel tiles per pixel
     // tile; halo form: 13x13 blocks per image and per block row
     uint32_t tc_mul, tc_shift, bpi_mul, bpi_shift, bpr_mul, bpr_shift;
@@ -132,7 +134,7 @@ bool conv_halo_cfg_ok(const ConvArgs &a, int cfg);       // ... and the block sh
 bool conv_cfg_is_halo(int cfg);
 hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_halo13_diag(const ConvArgs &a, hipStream_t s, int variant = 0);   // 0: eight waves of 176 x 32 (the shipped shape), 1: four waves of 176 x 64      // stamped free-running 176x256 build (tools only)
-bool conv_cfg_tail_ok(int cfg, int cout, bool fp8);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
+bool conv_cfg_tail_ok(int cfg, int cout, bool fp8, bool head = false);      // can tile configuration `cfg` run the fused 1x1 tail for a conv with `cout` channels
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
 bool conv_cfg_split_ok(int cfg);      // tile configurations instantiated for split fp16 storage (YOLO_FP16X2)

@@ -156,8 +156,8 @@ int tail_fragments(yolo_ctx *c)
     for (auto &T : c->layers) {
         if (T.type != L_CONV || T.fused_into < 0) continue;
         if (T.in_dt != DT_BF16 && T.in_dt != DT_F16) continue;          // (16-bit tails only; also the bf16 islands of a mixed e4m3 plan)
-        const int C2 = T.filters, K = T.kpad;                        // K == the producer's channel count, a multiple of 32
-        if (C2 % 16 || K % 32) continue;
+        const int C2 = roundup(T.filters, 16), K = T.kpad;           // K == the producer's channel count, a multiple of 32 (a head's 255 filters: 256 rows, the last one zero)
+        if (C2 > T.cout_pad || K % 32) continue;
         src.resize((size_t)T.cout_pad * K); dst.resize((size_t)C2 * K);
         HIPCK(c, hipMemcpy(src.data(), T.d_w, src.size() * 2, hipMemcpyDeviceToHost));
         const int K2S = K / 32;

@@ -279,6 +279,10 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             Layer &T = c->layers[j];
             if (T.type == L_CONV && !T.fc && T.in[0] == o && T.size == 1 && T.stride == 1 && T.pad == 0 && T.filters * 2 == P.filters && !T.head &&
                 T.residual_from < -1 && !T.stem_tail && !T.blk_skip && T.in_dt == P.in_dt && !T.pair) { P.tail_layer = j; T.fused_into = i; }      // (same operand type: the tail runs on the producer's MFMA)
+            // round 5: a detection head (1x1, <= 256 filters, fp32 out, linear) as the tail of the 256-channel 3x3 in front of it when nobody else
+            // reads that conv (darknet-53's 52 x 52 head): the head tensor is formed from the tile in LDS, bit-identical to the stand-alone launch
+            else if (T.type == L_CONV && !T.fc && T.head && T.in[0] == o && uses[o] == 1 && T.size == 1 && T.stride == 1 && T.pad == 0 && P.filters == 256 && T.filters <= 256 &&
+                     P.size == 3 && P.residual_from < -1 && T.act == ACT_LINEAR && T.in_dt == P.in_dt && (T.in_dt == DT_BF16 || T.in_dt == DT_F16) && !getenv("YOLO_NO_HEAD_TAIL") && j + 1 < NL && c->layers[j + 1].type == L_YOLO) { P.tail_layer = j; T.fused_into = i; }
         }
     }
     // storage assignment: st_of[i] = storage holding layer i's output

@@ -31,6 +31,10 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
         const Layer &T = c->layers[L.tail_layer];
         a.w2 = T.d_w; a.w2f = T.d_wf; a.b2 = T.d_b; a.out2 = T.out.ptr; a.out2_stride = T.out.stride; a.K2pad = T.kpad; a.act2 = T.act;
         a.oscale2 = T.d_sc; a.out2_inv_scale = T.out.dt == DT_FP8 ? 1.f / c->eff_scale[L.tail_layer] : 1.f;
+        if (T.head) {            // the tail is a detection head: fp32 rows + the objectness plane of the [yolo] layer behind it
+            a.tail_f32 = 1; a.C2out = T.filters;
+            if (T.d_obj && L.tail_layer + 1 < (int)c->layers.size()) { const Layer &Y = c->layers[L.tail_layer + 1]; a.obj_out = T.d_obj; a.obj_attrs = 5 + Y.classes; a.obj_na = Y.na; conv_magic((uint32_t)a.obj_attrs, a.obj_mul, a.obj_shift); }
+        }
     }
     if (L.out.dt == DT_FP8) {
         if (L.residual_from >= -1) {     // fused shortcut: this conv writes layer li+1's tensor
@@ -133,13 +137,13 @@ int run_layer(yolo_ctx *c, int i, int n)
         else if (L.in_dt == DT_FP8) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_fp8_ok(L.tile_cfg) ? L.tile_cfg : conv_pick_cfg(a);
             if (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg)) cfg = conv_pick_cfg(a);      // e.g. a smaller batch window or another input size
-            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8, a.tail_f32 != 0)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_fp8(a, cfg, s));
         } else {
             int cfg = L.tile_cfg >= 0 ? L.tile_cfg : conv_pick_cfg(a);
             if (cfg == CONV_CFG_DIRECT && !conv_c8_direct_ok(a)) cfg = conv_pick_cfg(a);
             if (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg)) cfg = conv_pick_cfg(a);
-            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
+            if (a.w2 && !conv_cfg_tail_ok(cfg, a.Cout, a.in_dt == DT_FP8, a.tail_f32 != 0)) return fail(c, YOLO_ERR_STATE, "layer %d: tile config %d cannot run the fused 1x1 tail", i, cfg);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
         break; }
@@ -583,11 +587,12 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         std::vector<float> base(ms);
         std::vector<int> base_cfg(NL, -1);
         for (int i = 0; i < NL; ++i) base_cfg[i] = c->layers[i].tile_cfg;
-        std::map<std::string, std::pair<double, int>> best;         // producer shape -> (pair time, cfg), cfg -1 = unfused
+        std::map<std::string, std::pair<double, int>> best;         // producer shape (+ kind of tail) -> (pair time, cfg), cfg -1 = unfused
+        auto tail_key = [&](const Layer &L) { return shape_key(L) + (c->layers[L.tail_layer].head ? "_head" : ""); };      // (a head as the tail: another set of configurations can host it)
         for (int i = 0; i < NL; ++i) {
             const Layer &L = c->layers[i];
             if (L.type != L_CONV || L.tail_layer < 0) continue;
-            auto &b = best[shape_key(L)];
+            auto &b = best[tail_key(L)];
             if (b.second == 0 && b.first == 0) b = {0.0, -1};
             b.first += base[i] + base[L.tail_layer];
         }
@@ -596,7 +601,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             for (int i = 0; i < NL; ++i) {
                 Layer &L = c->layers[i];
                 if (L.type != L_CONV || L.tail_layer < 0) continue;
-                bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8) && c->layers[L.tail_layer].in_dt == L.in_dt && valid(L, cfg);      // (valid: e.g. a shape the e4m3 table does not instantiate)
+                bool ok = conv_cfg_tail_ok(cfg, L.filters, L.in_dt == DT_FP8, c->layers[L.tail_layer].head) && c->layers[L.tail_layer].in_dt == L.in_dt && valid(L, cfg);      // (valid: e.g. a shape the e4m3 table does not instantiate)
                 if (ok && conv_cfg_is_halo(cfg)) { ConvArgs a = conv_args(c, L, n); ok = conv_halo_cfg_ok(a, cfg); }
                 L.tile_cfg = ok ? cfg : base_cfg[i]; L.tail_on = ok; any |= ok;
             }
@@ -605,7 +610,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
             std::map<std::string, double> t;
             for (int i = 0; i < NL; ++i) {
                 const Layer &L = c->layers[i];
-                if (L.type == L_CONV && L.tail_layer >= 0 && L.tail_on) t[shape_key(L)] += ms[i] + ms[L.tail_layer];
+                if (L.type == L_CONV && L.tail_layer >= 0 && L.tail_on) t[tail_key(L)] += ms[i] + ms[L.tail_layer];
             }
             for (auto &kv : t) {
                 auto &b = best[kv.first];
@@ -616,7 +621,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
         for (int i = 0; i < NL; ++i) {
             Layer &L = c->layers[i];
             if (L.type != L_CONV || L.tail_layer < 0) continue;
-            const auto &b = best[shape_key(L)];
+            const auto &b = best[tail_key(L)];
             L.tail_on = b.second >= 0; L.tile_cfg = b.second >= 0 ? b.second : base_cfg[i];
         }
     }
@@ -643,7 +648,7 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
         int v = cfgs[i]; bool tail = false;
         if (v >= 10000) { v -= 10000; tail = true; }
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
-        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->layers[i].in_dt == DT_FP8) || c->layers[c->layers[i].tail_layer].in_dt != c->layers[i].in_dt))
+        if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->layers[i].in_dt == DT_FP8, c->layers[c->layers[i].tail_layer].head) || c->layers[c->layers[i].tail_layer].in_dt != c->layers[i].in_dt))
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
         if (tail && conv_cfg_is_halo(v)) {
             ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
