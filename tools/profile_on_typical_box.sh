@@ -1,5 +1,5 @@
 # One gpurun call: probe the box with a short bench run and, if it is at least as fast as a typical box (MINV img/s, default 12300), run the
-# round-4 profile rounds of round ${R:-r05} (headline set + BASELINE config 4 per-GPU share) on it.  Boxes differ by up to 9 % on one binary.
+# profile rounds of round r05 (headline set + BASELINE config 4 per-GPU share) on it.  Boxes differ by up to 9 % on one binary (docs/NOTEBOOK.md).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 python3 bench.py --no-cpu-baseline --parity-images 0 --steps 30 > gpurun_out/m_probe.json 2>/dev/null
