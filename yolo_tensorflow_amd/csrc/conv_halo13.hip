@@ -30,17 +30,18 @@ static bool halo_ok(const ConvArgs &a, int bh, int bw)
     return (double)a.N * a.H * a.W * a.in_stride * dt_size(a.in_dt) < 2147483648.0;
 }
 
-template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B>
+template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false>
 static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
 {
+    if (a.tail_f32 && !HEADT) return hipErrorInvalidValue;        // a head as the tail runs on the HEADT instantiations (tile configurations 40 and 54)
     constexpr int WP = 1, TP = (BH * BW + 15) / 16, BK = 64, BC = WC * TC * 16;
     const long blocks = (long)a.N * ((a.H + BH - 1) / BH) * ((a.W + BW - 1) / BW);
     const long tiles = blocks * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL, true, BH, BW>();
     static_assert(lds <= 160 * 1024, "halo form: LDS");
-    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW>, lds);
+    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, BH, BW));
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, BH, BW));
     return hipGetLastError();
 }
 
@@ -74,7 +75,8 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
         const bool h = a.in_dt == DT_F16;
         if (h && a.out_dt != DT_F16) return hipErrorInvalidValue;
         switch (cfg) {
-        case 54: return h ? launch_h<8, 2, 0, 2, true, 2, true, false, 10, 19>(a, s) : launch_h<8, 2, 0, 2, true, 2, false, false, 10, 19>(a, s);
+        case 54: if (a.tail_f32) return h ? launch_h<8, 2, 0, 2, true, 2, true, false, 10, 19, true>(a, s) : launch_h<8, 2, 0, 2, true, 2, false, false, 10, 19, true>(a, s);
+                 return h ? launch_h<8, 2, 0, 2, true, 2, true, false, 10, 19>(a, s) : launch_h<8, 2, 0, 2, true, 2, false, false, 10, 19>(a, s);
         case 55: return h ? launch_h<8, 1, 0, 2, true, 3, true, false, 10, 19>(a, s) : launch_h<8, 1, 0, 2, true, 3, false, false, 10, 19>(a, s);
         default: return h ? launch_h<8, 1, 0, 2, true, 3, true, false, 5, 19>(a, s) : launch_h<8, 1, 0, 2, true, 3, false, false, 5, 19>(a, s);
         }
@@ -95,7 +97,7 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
         case 37: return launch_h<8, 2, 4, 2, false, 2, true>(a, s);
         case 38: return launch_h<4, 2, 4, 2, false, 2, true>(a, s);
         case 39: return launch_h<4, 2, 0, 2, false, 2, true>(a, s);
-        case 40: return launch_h<8, 2, 0, 2, true, 2, true>(a, s);
+        case 40: return a.tail_f32 ? launch_h<8, 2, 0, 2, true, 2, true, false, HALO_B, HALO_B, true>(a, s) : launch_h<8, 2, 0, 2, true, 2, true>(a, s);
         case 41: return launch_h<8, 1, 0, 2, true, 2, true>(a, s);
         case 42: return launch_h<4, 2, 0, 2, true, 2, true>(a, s);
         case 43: return launch_h<8, 1, 0, 2, true, 3, true>(a, s);
@@ -107,7 +109,7 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
     case 37: return f8 ? launch_h<8, 2, 4, 1>(a, s) : launch_h<8, 2, 4, 2>(a, s);
     case 38: return f8 ? launch_h<4, 2, 4, 1>(a, s) : launch_h<4, 2, 4, 2>(a, s);
     case 39: return f8 ? launch_h<4, 2, 0, 1>(a, s) : launch_h<4, 2, 0, 2>(a, s);
-    case 40: return f8 ? launch_h<8, 2, 0, 1, true>(a, s) : launch_h<8, 2, 0, 2, true>(a, s);
+    case 40: return f8 ? launch_h<8, 2, 0, 1, true>(a, s) : a.tail_f32 ? launch_h<8, 2, 0, 2, true, 2, false, false, HALO_B, HALO_B, true>(a, s) : launch_h<8, 2, 0, 2, true>(a, s);
     case 41: return f8 ? launch_h<8, 1, 0, 1, true>(a, s) : launch_h<8, 1, 0, 2, true>(a, s);
     case 42: return f8 ? launch_h<4, 2, 0, 1, true>(a, s) : launch_h<4, 2, 0, 2, true>(a, s);
     case 43: return f8 ? launch_h<8, 1, 0, 1, true, 3>(a, s) : launch_h<8, 1, 0, 2, true, 3>(a, s);

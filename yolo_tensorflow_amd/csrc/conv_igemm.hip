@@ -240,7 +240,7 @@ bool conv_cfg_tail_ok(int cfg, int cout, bool fp8, bool head)
     if (cfg < 0 || cfg >= conv_num_cfgs()) return false;
     const CfgDesc &c = kCfgs[cfg];
     const int bc = c.wc * c.tc * 16;
-    if (head) return !fp8 && c.halo && c.wp == 1 && c.wc == 8 && c.nl == 0 && bc == 256 && cout == 256;      // a head as the tail: the halo forms' two-channel-tile waves
+    if (head) return !fp8 && (cfg == 40 || cfg == 54) && cout == 256;      // a head as the tail: the free-running 176 x 256 / 10 x 19 x 256 halo forms have a HEADT instantiation
     return c.wp == 1 && c.wc == 8 && (fp8 ? bc == 256 : c.nl == 0 && (bc == 256 || bc == 128)) && bc == cout;      // (as TAIL_OK in the kernel)
 }
 const char *conv_cfg_name(int cfg)

@@ -163,7 +163,7 @@ constexpr bool halo_div_ok(int bw) { for (unsigned r = 0; r < 256; ++r) if (((r 
 // into block 1 (blocks a.out_blk elements apart) -- by an epilogue of its own that stages the tile in LDS as fp32, half its channels at a time,
 // and folds the shortcut; the K loop is the ordinary fp16 one, run over the 3 x Cin 'channels' hi | lo | hi of the input against filter rows
 // W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B>
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -896,7 +896,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         constexpr int C2 = BC / 2, K2S = BC / 32, T2W = HALO ? 2 : 1, T2G = (C2 / (16 * T2W)) > 0 ? C2 / (16 * T2W) : 1, T2P = 8 / T2G > 0 ? 8 / T2G : 1;
         // (round 5) the tail may be a detection HEAD (a.tail_f32; halo forms with BC = 256 only): up to 256 filters, so every wave owns its own
         // 32 of them for ALL pixel sub-tiles, and the result leaves as fp32 rows straight from the accumulators, as the stand-alone head does
-        constexpr bool HEAD_TAIL_OK = TAIL_OK && EB == 2 && HALO && BC == 256;
+        // HEADT: its own instantiation -- as a run-time mode of the ordinary tail kernels the extra code cost THEIR layers 1 % (same-box A/B)
+        constexpr bool HEAD_TAIL_OK = HEADT && TAIL_OK && EB == 2 && HALO && BC == 256;
         const bool head_tail = HEAD_TAIL_OK && a.tail_f32;
         const int t2g = head_tail ? wave_id : wave_id % T2G, t2p = head_tail ? 0 : wave_id / T2G;
         bf16x8 fw2[TAIL_OK && EB == 2 ? T2W : 1][TAIL_OK && EB == 2 ? K2S : 1];
