@@ -15,6 +15,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_c_abi_sharded_detect_world1(hiplib):
+    """include/yolo_dist.h on the GPU: yolo_dist_unique_id -> yolo_dist_create (ncclCommInitRank through the library's run-time RCCL
+    binding) -> yolo_dist_detect (graph-replayed local step into the flat record buffer, ncclAllGather on the context's stream, split on
+    the host) returns exactly what the plain detect step returns.  World size 1 is the only world a one-GPU box offers; the split of a
+    gathered buffer over many ranks is covered on the CPU (tests/test_host.py) against the torch.distributed host."""
+    import torch
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 96)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=12)
+    img = np.random.default_rng(16).integers(0, 256, (3, 96, 96, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=4)
+    eng.set_weights(flat)
+    want = eng.detect(img, score_thr=0.3, iou_thr=0.5, max_out=20, nms_mode=hiplib.NMS_TF)
+    assert sum(len(w) for w in want) > 5
+    sd = hiplib.ShardedDetector(eng, 1, 0, hiplib.dist_unique_id(), global_batch=3, max_out=20)
+    dimg = torch.from_numpy(img).cuda()
+    for _ in range(4):                                            # eager, capture, replays
+        got = sd.detect(dimg, score_thr=0.3, iou_thr=0.5, nms_mode=hiplib.NMS_TF)
+    assert len(got) == 3 and all(np.array_equal(g, w) for g, w in zip(got, want))
+    with pytest.raises(hiplib.YoloError, match="images"):
+        sd.detect(dimg[:2], score_thr=0.3)
+    sd.close()
+    with pytest.raises(hiplib.YoloError, match="planned for"):
+        hiplib.ShardedDetector(eng, 1, 0, hiplib.dist_unique_id(), global_batch=5)
+    eng.close()
+
+
 def test_rccl_gather_of_device_records_world1(hiplib):
     import torch
     import torch.distributed as dist

@@ -76,6 +76,33 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(hip._Config) == 48 and hip.BOX_DTYPE.itemsize == 24
 
 
+def test_sharding_entry_points_match_the_python_host():
+    """include/yolo_dist.h: every declared symbol is exported and bound; the C split of the batch and of the gathered record
+    buffers equals yolo_tensorflow_amd/dist.py's (what bench.py runs over torch.distributed), ragged splits included."""
+    import torch
+    from yolo_tensorflow_amd import hip, dist
+    lib = hip.load_library()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "yolo_dist.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(yolo_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(hip.DIST_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), "libyolo_hip.so does not export " + name
+    rng = np.random.default_rng(5)
+    for world, batch, max_out in [(1, 3, 20), (2, 32, 20), (3, 8, 5), (4, 2, 7), (8, 64, 20), (8, 33, 3)]:
+        for r in range(world):
+            assert hip.shard_bounds(batch, world, r) == dist.shard_bounds(batch, world, r)
+        per = -(-batch // world)
+        flat = per * max_out * 6 + per
+        assert lib.yolo_dist_flat_words(per, max_out) == flat
+        gathered = rng.integers(-2**31, 2**31 - 1, (world, flat), dtype=np.int64).astype(np.int32)
+        boxes, counts = hip.dist_split_records(gathered, world, batch, max_out)
+        tb, tc = dist.split_flat_records_ragged(torch.from_numpy(gathered), batch, max_out)
+        assert np.array_equal(boxes.view(np.int32).reshape(batch, max_out * 6), tb.numpy()) and np.array_equal(counts, tc.numpy())
+    first, count = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.yolo_shard_bounds(8, 2, 2, ctypes.byref(first), ctypes.byref(count)) == -1      # rank outside the world
+    assert lib.yolo_dist_create(None, 1, 0, None, None, 1, 1, None, 0) is None
+
+
 @pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback_without_device():
     from yolo_tensorflow_amd import hip

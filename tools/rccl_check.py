@@ -1,7 +1,8 @@
 """RCCL exchange check on real GPUs: every rank runs the detect path on its shard of a global batch (device-resident images,
 box records written in place by the library), then ONE all_gather_into_tensor of the flat record buffers
 (yolo_tensorflow_amd/dist.py, the call bench.py makes); every rank must end up with exactly the records a single engine
-produces for the whole batch.
+produces for the whole batch.  The same step is then run behind the C ABI (include/yolo_dist.h: yolo_dist_create /
+yolo_dist_detect on a communicator the library initialises itself) on a ragged global batch.
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/rccl_check.py
 
@@ -21,6 +22,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 def run_check(rank, world, local_rank, n_local=4, size=160, max_out=10):
     import torch
+    import torch.distributed as dist
     from yolo_tensorflow_amd import hip, darknet_io as IO, dist as ydist
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -60,6 +62,19 @@ def run_check(rank, world, local_rank, n_local=4, size=160, max_out=10):
     dets = ydist.unpack_records(full, hip.BOX_DTYPE, max_out)
     for i in range(n_local * world):
         assert np.array_equal(dets[i], want[i])
+    # the same step behind the C ABI (include/yolo_dist.h): the library's own RCCL communicator, a RAGGED global batch (one image
+    # fewer than the ranks can hold), the 128-byte id handed out through the process group
+    B = n_local * world - (1 if world > 1 else 0)
+    ids = [hip.dist_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    sd = hip.ShardedDetector(eng, world, rank, ids[0], global_batch=B, max_out=max_out)
+    clo, chi = hip.shard_bounds(B, world, rank)
+    cimg = torch.from_numpy(all_img[clo:chi]).to(dev)
+    for _ in range(3):
+        got = sd.detect(cimg, score_thr=0.3, iou_thr=0.5)
+    for i in range(B):
+        assert np.array_equal(got[i], want[i]), "rank %d: image %d differs after yolo_dist_detect" % (rank, i)
+    sd.close()
     eng.close()
     return True
 

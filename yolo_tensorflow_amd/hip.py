@@ -35,6 +35,9 @@ EXPORTS = [
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
     "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw",
 ]
+# include/yolo_dist.h: the image-sharded detect step
+DIST_EXPORTS = ["yolo_shard_bounds", "yolo_dist_flat_words", "yolo_dist_split_records", "yolo_dist_unique_id", "yolo_dist_create",
+                "yolo_dist_detect", "yolo_dist_detect_async", "yolo_dist_destroy"]
 
 
 class YoloError(RuntimeError):
@@ -106,6 +109,14 @@ def load_library():
     l.yolo_postprocess_rows.argtypes = [P, I, F, F, I, I, I, P, P, P, I]
     l.yolo_last_layer_output_batch.argtypes = [P, I, P, C.c_size_t]
     l.yolo_head_raw.argtypes = [P, I, I, P, C.c_size_t]
+    l.yolo_shard_bounds.argtypes = [I, I, I, C.POINTER(I), C.POINTER(I)]
+    l.yolo_dist_flat_words.argtypes = [I, I]; l.yolo_dist_flat_words.restype = C.c_size_t
+    l.yolo_dist_split_records.argtypes = [P, I, I, I, P, P]
+    l.yolo_dist_unique_id.argtypes = [P]
+    l.yolo_dist_create.argtypes = [P, I, I, P, P, I, I, C.c_char_p, C.c_size_t]; l.yolo_dist_create.restype = P
+    l.yolo_dist_detect.argtypes = [P, P, I, F, F, F, I, I, P, P]
+    l.yolo_dist_detect_async.argtypes = [P, P, I, F, F, F, I, I, C.POINTER(P)]
+    l.yolo_dist_destroy.argtypes = [P]; l.yolo_dist_destroy.restype = None
     _lib = l
     return l
 
@@ -472,3 +483,66 @@ def op_postprocess(det, score_thr, iou_thr, max_out, nms_mode=NMS_TF, select_mod
     if return_rows:
         return recs, [ridx[i, :counts[i]].copy() for i in range(n)]
     return recs
+
+
+# ---- include/yolo_dist.h: the image-sharded detect step behind the C ABI ----
+def shard_bounds(global_batch, world_size, rank):
+    """yolo_shard_bounds: (lo, hi) of rank's contiguous slice of the global batch."""
+    first, count = C.c_int(0), C.c_int(0)
+    _op_check(load_library().yolo_shard_bounds(global_batch, world_size, rank, C.byref(first), C.byref(count)), "yolo_shard_bounds")
+    return first.value, first.value + count.value
+
+
+def dist_split_records(gathered, world_size, global_batch, max_out):
+    """yolo_dist_split_records: gathered int32 [world, flat] (host) -> (boxes [global_batch, max_out] records, counts [global_batch])."""
+    lib = load_library()
+    per = -(-global_batch // world_size)
+    g = np.ascontiguousarray(gathered, dtype=np.int32)
+    if g.size != world_size * lib.yolo_dist_flat_words(per, max_out):
+        raise YoloError("gathered buffer holds %d words, %d ranks x %d expected" % (g.size, world_size, lib.yolo_dist_flat_words(per, max_out)))
+    boxes = np.zeros((global_batch, max_out), dtype=BOX_DTYPE)
+    counts = np.zeros(global_batch, dtype=np.int32)
+    _op_check(lib.yolo_dist_split_records(g.ctypes.data, world_size, global_batch, max_out, boxes.ctypes.data, counts.ctypes.data),
+              "yolo_dist_split_records")
+    return boxes, counts
+
+
+def dist_unique_id():
+    """yolo_dist_unique_id: the 128 bytes rank 0 hands to every rank's ShardedDetector."""
+    buf = (C.c_uint8 * 128)()
+    _op_check(load_library().yolo_dist_unique_id(buf), "yolo_dist_unique_id (RCCL)")
+    return bytes(buf)
+
+
+class ShardedDetector(object):
+    """yolo_dist_*: this rank's Engine bound to a communicator of `world_size` ranks.  detect(images) takes THIS rank's slice
+    (device tensor) and returns the whole batch's per-image record arrays, in global image order, on every rank."""
+
+    def __init__(self, engine, world_size, rank, unique_id, global_batch, max_out=20):
+        self.lib = load_library()
+        self.engine = engine
+        self.global_batch, self.max_out, self.world_size, self.rank = global_batch, max_out, world_size, rank
+        self.lo, self.hi = shard_bounds(global_batch, world_size, rank)
+        err = C.create_string_buffer(512)
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self.h = self.lib.yolo_dist_create(engine.ctx, world_size, rank, idbuf, None, global_batch, max_out, err, 512)
+        if not self.h:
+            raise YoloError("yolo_dist_create: " + err.value.decode())
+
+    def detect(self, images, scale=1.0 / 255.0, score_thr=0.5, iou_thr=0.5, nms_mode=NMS_TF, select_mode=SELECT_GT):
+        p, loc = _ptr(images)
+        if self.hi > self.lo and (loc != DEVICE or int(images.shape[0]) != self.hi - self.lo):
+            raise YoloError("rank %d serves images [%d, %d): a device tensor of that many images is needed" % (self.rank, self.lo, self.hi))
+        self._images = images                       # the graph replays from this buffer: keep it alive
+        self.engine._order_after_producer(images)
+        fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
+        boxes = np.zeros((self.global_batch, self.max_out), dtype=BOX_DTYPE)
+        counts = np.zeros(self.global_batch, dtype=np.int32)
+        self.engine._check(self.lib.yolo_dist_detect(self.h, p, fmt, scale, score_thr, iou_thr, nms_mode, select_mode,
+                                                      boxes.ctypes.data, counts.ctypes.data), "yolo_dist_detect")
+        return [boxes[i, :counts[i]].copy() for i in range(self.global_batch)]
+
+    def close(self):
+        if self.h:
+            self.lib.yolo_dist_destroy(self.h)
+            self.h = None
