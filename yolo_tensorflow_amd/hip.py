@@ -534,8 +534,10 @@ class ShardedDetector(object):
         if self.hi > self.lo and (loc != DEVICE or int(images.shape[0]) != self.hi - self.lo):
             raise YoloError("rank %d serves images [%d, %d): a device tensor of that many images is needed" % (self.rank, self.lo, self.hi))
         self._images = images                       # the graph replays from this buffer: keep it alive
-        self.engine._order_after_producer(images)
-        fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
+        fmt = IMG_U8
+        if images is not None:                      # (a rank whose slice is empty -- more ranks than images -- only takes part in the gather)
+            self.engine._order_after_producer(images)
+            fmt = IMG_U8 if str(images.dtype).endswith("uint8") else IMG_F32
         boxes = np.zeros((self.global_batch, self.max_out), dtype=BOX_DTYPE)
         counts = np.zeros(self.global_batch, dtype=np.int32)
         self.engine._check(self.lib.yolo_dist_detect(self.h, p, fmt, scale, score_thr, iou_thr, nms_mode, select_mode,
