@@ -103,6 +103,20 @@ def test_sharding_entry_points_match_the_python_host():
     assert lib.yolo_dist_create(None, 1, 0, None, None, 1, 1, None, 0) is None
 
 
+def test_plain_c_consumer_of_the_abi(tmp_path):
+    """tests/c/abi_consumer.c: the public headers compile as C99 (-pedantic), the libraries link from C, and the host-side entry
+    points return codes a C caller can act on.  No device call is made."""
+    import subprocess
+    exe = str(tmp_path / "abi_consumer")
+    libdir = os.path.join(ROOT, "yolo_tensorflow_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "c", "abi_consumer.c"), "-o", exe, "-L" + libdir, "-lyolo_hip", "-ldarknet_hip",
+                         "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "abi_consumer ok" in run.stdout, run.stderr
+
+
 @pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback_without_device():
     from yolo_tensorflow_amd import hip
