@@ -22,16 +22,15 @@ struct Rccl {
     std::string why;
 };
 
-Rccl &rccl()
+Rccl load_rccl()
 {
-    static Rccl r;
-    if (r.so || !r.why.empty()) return r;
+    Rccl r;
     const char *names[] = {getenv("YOLO_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         if (!n || !*n) continue;
         if ((r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     }
-    if (!r.so) { r.why = "RCCL not found (set YOLO_RCCL_LIB): "; r.why += dlerror() ? dlerror() : "dlopen failed"; return r; }
+    if (!r.so) { const char *e = dlerror(); r.why = "RCCL not found (set YOLO_RCCL_LIB): "; r.why += e ? e : "dlopen failed"; return r; }
     auto sym = [&](const char *s) { void *p = dlsym(r.so, s); if (!p && r.why.empty()) { r.why = "RCCL lacks "; r.why += s; } return p; };
     r.GetUniqueId = (int (*)(UniqueId *))sym("ncclGetUniqueId");
     r.CommInitRank = (int (*)(Comm *, int, UniqueId, int))sym("ncclCommInitRank");
@@ -39,6 +38,13 @@ Rccl &rccl()
     r.AllGather = (int (*)(const void *, void *, size_t, int, Comm, hipStream_t))sym("ncclAllGather");
     r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
     if (!r.why.empty()) { dlclose(r.so); r.so = nullptr; }
+    return r;
+}
+
+// bound once, on first use (a function-local static: initialised exactly once even when contexts on several threads get here together)
+const Rccl &rccl()
+{
+    static const Rccl r = load_rccl();
     return r;
 }
 
@@ -97,7 +103,7 @@ int yolo_dist_split_records(const int32_t *gathered, int world_size, int global_
 int yolo_dist_unique_id(uint8_t id[128])
 {
     if (!id) return YOLO_ERR_INVALID;
-    Rccl &r = rccl();
+    const Rccl &r = rccl();
     if (!r.so) return YOLO_ERR_UNSUPPORTED;
     UniqueId u;
     if (r.GetUniqueId(&u) != 0) return YOLO_ERR_HIP;
@@ -116,7 +122,7 @@ yolo_dist *yolo_dist_create(yolo_ctx *ctx, int world_size, int rank, const uint8
     const int per = (global_batch + world_size - 1) / world_size;
     if (per > ctx->max_batch) return bad(eb, "yolo_dist_create: %d images per rank, the context was planned for %d", per, ctx->max_batch);
     if (!comm && !id) return bad(eb, "yolo_dist_create needs the caller's ncclComm_t or the 128-byte id of yolo_dist_unique_id");
-    Rccl &r = rccl();
+    const Rccl &r = rccl();
     if (!r.so) return bad(eb, "yolo_dist_create: %s", r.why.c_str());
     if (hipSetDevice(ctx->device) != hipSuccess) return bad(eb, "yolo_dist_create: hipSetDevice(%d) failed", ctx->device);
     yolo_dist *d = new yolo_dist;
