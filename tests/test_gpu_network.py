@@ -418,6 +418,31 @@ num=3
 """
 
 
+@pytest.mark.parametrize("size,batch,shortcut", [(416, 12, True), (400, 7, False), (400, 5, True), (80, 3, False)])
+def test_halo32_ring_of_tiles_equals_the_tiled_kernel(hiplib, monkeypatch, size, batch, shortcut):
+    """conv_halo_c32_c64 keeps input and shortcut tiles of TWO tiles ahead in flight (rings of three LDS slots, one counted vmcnt per
+    tile): run it deep into its steady state -- up to 16 tiles per workgroup, with and without the shortcut, on grids its 8 x 16 tiles
+    cover exactly (208 x 208) and raggedly (200 = 12.5 x 16; 40 = 2.5 x 16: the out-of-image stores are issued and dropped) -- and compare the whole first stage with the
+    plan that runs the same layer through the tiled kernel (YOLO_NO_HALO): same K order, bit-identical."""
+    txt = STEM_NET.replace("width=416", "width=%d" % size).replace("height=416", "height=%d" % size)
+    if not shortcut:
+        txt = txt.replace("[shortcut]\nfrom=-3\nactivation=linear\n\n", "")
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=21)
+    img = np.random.default_rng(size + batch).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    outs = []
+    for no_halo in (False, True):
+        if no_halo: monkeypatch.setenv("YOLO_NO_HALO", "1")
+        else: monkeypatch.delenv("YOLO_NO_HALO", raising=False)
+        eng = hiplib.Engine(txt, max_batch=batch, keep_layers=True)
+        eng.set_weights(flat)
+        eng.forward(img)
+        last = 4 if shortcut else 3
+        outs.append(eng.layer_output(last, batch))
+        eng.close()
+    assert outs[0].shape == (batch, size // 2, size // 2, 64) and np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_stem_and_halo_kernels_at_full_size_vs_oracle(hiplib):
     """The two special kernels of the first stage at their real geometry (416x416 in, 208x208 out, batch 2): conv_stem_c32_c64
     (conv0 + conv1 + conv2 in one launch) and conv_halo_c32_c64 (conv3 + shortcut).  (a) every layer of the layer-by-layer

@@ -446,6 +446,10 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_stem_c32_c64(const StemArgs a
 // DMA'd into LDS at the start of its tile and added in the store pass (conv output rounded to bf16 first, as everywhere).
 // LDS pixel records are 64 B with the 16-B chunk index XOR 2*((pixel>>2)&1): conflict-free for ds_read_b128's lane groups
 // at pixel stride 1.  HBM-bound by design: input once, shortcut once, output once.
+// A tile is ~0.5 us of work against ~2 us of memory latency, so input AND shortcut tiles are requested TWO tiles ahead into rings of
+// three LDS slots each (27.5 KB per tile: 55 KB in flight per CU, 14 MB on the chip); the one counted vmcnt of a tile waits for the
+// requests of the tile before it only.  (With the shortcut requested at the start of its own tile and a vmcnt(0) behind nine taps of
+// MFMAs, every tile paid one whole round trip: 2.5 us per tile, 4.2 TB/s.)
 constexpr int HL_IH = ST_TH + 2, HL_IW = ST_TW + 2;          // 10 x 18 input pixels
 constexpr int HL_INPIX = HL_IH * HL_IW;                      // 180
 constexpr int HL_INCHUNKS = (HL_INPIX * 4 + 63) / 64;        // 16-B pieces / 64 lanes: 12 LDS-DMA instructions
@@ -504,16 +508,19 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
             const int q = (wave + ST_NW * k) * 64 + lane;
             const int px = q >> 3, pc = q & 7;
             const int oy = ty * ST_TH + (px >> 4), ox = tx * ST_TW + (px & 15);
-            const bool ok = oy < a.H && ox < a.W;
+            const bool ok = tile < ntiles && oy < a.H && ox < a.W;
             const unsigned off = ok ? (unsigned)(((n * a.H + oy) * a.W + ox) * a.res_stride + pc * 8) * 2u : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, (st_lds_void *)(dst + (wave + ST_NW * k) * 1024), 16, off, 0, 0, 0);
         }
     };
 
-    auto do_tile = [&](int tile, int next_tile, char *__restrict__ in_next, const char *__restrict__ in_cur,
-                       char *__restrict__ lres, char *__restrict__ lo) {
-        fetch_in(next_tile, in_next);
-        if (a.res) fetch_res(tile, lres);
+    // every wave's vector-memory operations per tile, in issue order: 2 (waves 0-3) or 1 input pieces and 2 shortcut pieces for the tile
+    // two ahead, then (store pass) 2 stores
+    const bool has_res = a.res != nullptr;
+    auto do_tile = [&](int tile, int ahead_tile, char *__restrict__ in_fill, const char *__restrict__ in_cur,
+                       char *__restrict__ res_fill, const char *__restrict__ lres, char *__restrict__ lo) {
+        fetch_in(ahead_tile, in_fill);
+        if (has_res) fetch_res(ahead_tile, res_fill);
         const int n = tile / per_img, tr = tile - n * per_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
@@ -532,8 +539,12 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
         for (int ct = 0; ct < 4; ++ct) {
             *(uint2 *)(lo + (wave * ST_TW + l15) * ST_OPITCH + (ct * 16 + lq * 4) * 2) = stem_epi<H16>(acc[ct], bv[ct], slope);
         }
-        // staged tile complete, every wave done with this tile's input, next input and this tile's shortcut have landed
-        __builtin_amdgcn_s_waitcnt(0x0070);
+        // staged tile complete, every wave done with this tile's input; the next tile's input and this tile's shortcut (requested one
+        // and two tiles ago) must have landed.  Younger than the next tile's input pieces in this wave's queue: the next tile's shortcut
+        // pieces, the previous tile's two stores, the pieces requested at the top of this tile -- they may stay in flight (the first
+        // tile has no stores behind it; the start-up wait below has landed its tiles anyway)
+        if (has_res) { if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0077); }
+        else { if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0073); }
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int it = 0; it < ST_TH * ST_TW * 8 / (64 * ST_NW); ++it) {
@@ -552,24 +563,27 @@ __global__ __launch_bounds__(64 * ST_NW) void conv_halo_c32_c64(const HaloArgs a
                 }
                 o = uint4{ov[0], ov[1], ov[2], ov[3]};
             }
-            if (oy < a.H && ox < a.W)
-                out_store16_at(a.out, (unsigned)((((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8) * 2), o.x, o.y, o.z, o.w);       // (conv_halo_ok: the tensor is below 2 GiB)
+            // (conv_halo_ok: the tensor is below 2 GiB.  A pixel outside the image gets the out-of-range offset: the store is ISSUED and
+            // dropped by the bounds check, so that every wave issues exactly two stores per tile -- the counted wait above relies on it)
+            const unsigned so = (oy < a.H && ox < a.W) ? (unsigned)((((size_t)(n * a.H + oy) * a.W + ox) * a.out_stride + chunk * 8) * 2) : 0x80000000u;
+            out_store16_at(a.out, so, o.x, o.y, o.z, o.w);
         }
-        // the next tile writes `lo` / `lres` only after its own pre-store barrier / its fetch: `lres` is re-filled at the
-        // start of the next tile, so every thread must be past the reads above first
+        // the next tile writes `lo` only after its own pre-store barrier, and re-fills this tile's input / shortcut slots at its top:
+        // every thread must be past the reads above first
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
     };
 
-    char *const inb0 = smem, *const inb1 = smem + HL_IN_BYTES;
-    char *const lres = smem + 2 * HL_IN_BYTES, *const lo = lres + HL_RES_BYTES;
+    char *const inb = smem, *const resb = smem + 3 * HL_IN_BYTES, *const lo = resb + 3 * HL_RES_BYTES;
     int tile = blockIdx.x;
-    if (tile < ntiles) fetch_in(tile, inb0);
+    const int G = gridDim.x;
+    fetch_in(tile, inb); if (has_res) fetch_res(tile, resb);
+    fetch_in(tile + G, inb + HL_IN_BYTES); if (has_res) fetch_res(tile + G, resb + HL_RES_BYTES);
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        if (it & 1) do_tile(tile, tile + gridDim.x, inb0, inb1, lres, lo);
-        else do_tile(tile, tile + gridDim.x, inb1, inb0, lres, lo);
+    for (int slot = 0; tile < ntiles; tile += G, slot = slot == 2 ? 0 : slot + 1) {
+        const int fill = slot == 0 ? 2 : slot - 1;               // (slot + 2) % 3
+        do_tile(tile, tile + 2 * G, inb + fill * HL_IN_BYTES, inb + slot * HL_IN_BYTES, resb + fill * HL_RES_BYTES, resb + slot * HL_RES_BYTES, lo);
     }
 #endif
 }
@@ -585,7 +599,7 @@ bool conv_halo_ok(const HaloArgs &a)
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s)
 {
     if (!conv_halo_ok(a)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * HL_IN_BYTES + HL_RES_BYTES + ST_OUT_BYTES;
+    const size_t lds = (size_t)3 * HL_IN_BYTES + 3 * HL_RES_BYTES + ST_OUT_BYTES;
     const bool h16 = a.dt == DT_F16;
     { hipError_t e = conv_opt_in_lds(h16 ? (const void *)conv_halo_c32_c64<true> : (const void *)conv_halo_c32_c64<false>, lds); if (e != hipSuccess) return e; }
     const long tiles = (long)a.N * ((a.W + ST_TW - 1) / ST_TW) * ((a.H + ST_TH - 1) / ST_TH);
