@@ -443,6 +443,79 @@ def test_halo32_ring_of_tiles_equals_the_tiled_kernel(hiplib, monkeypatch, size,
     assert np.array_equal(outs[0], outs[1])
 
 
+S2_NET = """[net]
+width=208
+height=208
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=2
+pad=1
+activation=%s
+
+[maxpool]
+size=2
+stride=2
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+filters=255
+size=1
+stride=1
+pad=1
+activation=linear
+
+[yolo]
+mask=0,1,2
+anchors=10,13, 16,30, 33,23
+classes=80
+num=3
+"""
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
+@pytest.mark.parametrize("size,batch,act", [(208, 20, "leaky"), (72, 3, "leaky"), (40, 2, "linear"), (104, 33, "leaky")])
+def test_stride2_c64_kernel_equals_the_tiled_kernel_and_tracks_the_oracle(hiplib, monkeypatch, dtype_name, size, batch, act):
+    """conv_s2.hip (3x3 / stride 2, 64 -> 128: darknet-53's cfg layer 5; the window of a tile staged once in LDS two tiles ahead, filters
+    in registers) against the tiled kernel on the same layer (YOLO_NO_S2; same K order: bit-identical) deep into the ring of tiles (up to
+    22 per workgroup), on output grids its 8 x 8 tiles cover exactly (104, 52) and raggedly (36 = 4.5 x 8, 20 = 2.5 x 8), and against
+    the oracle at the device's storage precision (bf16)."""
+    txt = (S2_NET % act).replace("width=208", "width=%d" % size).replace("height=208", "height=%d" % size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=31)
+    img = np.random.default_rng(size + batch).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    dtype = hiplib.BF16 if dtype_name == "bf16" else hiplib.FP16
+    outs = []
+    for no_s2 in (False, True):
+        if no_s2: monkeypatch.setenv("YOLO_NO_S2", "1")
+        else: monkeypatch.delenv("YOLO_NO_S2", raising=False)
+        eng = hiplib.Engine(txt, max_batch=batch, dtype=dtype, keep_layers=True)
+        eng.set_weights(flat)
+        eng.forward(img)
+        outs.append(eng.layer_output(1, batch))
+        eng.close()
+    assert outs[0].shape == (batch, size // 2, size // 2, 128) and np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0], outs[1])
+    if dtype_name == "bf16" and batch <= 3:
+        osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)
+        _, ref = R.forward(osecs, params, R.to_bf16(img.astype(np.float32) / np.float32(255)), emulate_bf16=True, collect=True)
+        err = np.abs(outs[0] - ref[1])
+        assert (err <= 2.0 ** -6 * np.abs(ref[1]) + 4e-2).all() and float(err.mean()) < 2e-3
+
+
 def test_stem_and_halo_kernels_at_full_size_vs_oracle(hiplib):
     """The two special kernels of the first stage at their real geometry (416x416 in, 208x208 out, batch 2): conv_stem_c32_c64
     (conv0 + conv1 + conv2 in one launch) and conv_halo_c32_c64 (conv3 + shortcut).  (a) every layer of the layer-by-layer

@@ -167,6 +167,9 @@ struct HaloArgs {
 };
 bool conv_halo_ok(const HaloArgs &a);
 hipError_t launch_conv_halo(const HaloArgs &a, hipStream_t s);
+// 3x3 / stride 2 / pad 1, 64 -> 128 channels, 16-bit storage, no shortcut (conv_s2.hip): same arguments (H, W: the INPUT size; k = tap*64 + ci)
+bool conv_s2_ok(const HaloArgs &a);
+hipError_t launch_conv_s2(const HaloArgs &a, hipStream_t s);
 // fused residual block x + act2(conv3x3(act1(conv1x1(x)))), 128 -> 64 -> 128 channels, 16-bit storage (conv_block.hip)
 struct BlockArgs {
     const void *x; int x_stride;              // [N,H,W,>=128]: input of the 1x1 and source of the shortcut

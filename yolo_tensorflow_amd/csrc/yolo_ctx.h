@@ -43,6 +43,7 @@ struct Layer {
     bool blk_skip = false, blk = false;     // fused residual block (conv_block.hip): this 1x1 conv is computed inside the launch of the 3x3 conv that follows / this 3x3 conv launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one
+    bool s2 = false;                        // 3x3/s2, 64 -> 128 channels: window-staged kernel with register-resident filters (conv_s2.hip)
     // [connected] (YOLOv1's fully connected head, V1/YOLO_V1_Inference.py:196-206; DN/connected_layer.c:151): a 1x1 conv over the
     // producer's tensor flattened to one pixel per image; fc_h/w/c = the producer's geometry (darknet / the TF graph flatten CHW)
     bool fc = false; int fc_h = 0, fc_w = 0, fc_c = 0;

@@ -264,6 +264,10 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && !L.blk && L.size == 3 && L.stride == 1 && L.pad == 1 && L.cin == 32 && L.filters == 64 &&
                 is16(L.in_dt) && L.store_dt == L.in_dt && (L.residual_from < 0 || c->layers[L.residual_from].store_dt == L.in_dt) && !L.pair && !c->pair_of(L.in[0]))
                 L.halo = true;
+            // darknet-53's 64 -> 128 downsampling conv: window-staged, filters in registers (conv_s2.hip)
+            if (L.type == L_CONV && !L.head && !L.stem && !L.stem_skip && !L.stem_tail && !L.blk && !L.blk_skip && L.size == 3 && L.stride == 2 && L.pad == 1 && L.cin == 64 &&
+                L.filters == 128 && L.residual_from < -1 && is16(L.in_dt) && L.store_dt == L.in_dt && !L.pair && !c->pair_of(L.in[0]) && !getenv("YOLO_NO_S2"))
+                L.s2 = true;
         }
     // 1x1 convs that can ride in their producer's epilogue: conv i (bf16, 128 or 256 output channels, optionally with its
     // fused shortcut) read by a 1x1/s1 conv with half as many filters
@@ -463,6 +467,6 @@ int allocate(yolo_ctx *c)
     return YOLO_OK;
 }
 
-bool fixed_kernel(const Layer &L) { return L.stem || L.stem_skip || L.stem_tail || L.halo || L.blk || L.blk_skip; }
+bool fixed_kernel(const Layer &L) { return L.stem || L.stem_skip || L.stem_tail || L.halo || L.s2 || L.blk || L.blk_skip; }
 
 }  // namespace yolo_impl

@@ -128,6 +128,13 @@ int run_layer(yolo_ctx *c, int i, int n)
             if (conv_halo_ok(h)) { HIPCK(c, launch_conv_halo(h, s)); break; }
             // window over 2 GiB (very large batches): the tiled kernel below checks its own window
         }
+        if (L.s2) {            // 3x3/s2 64 -> 128: window staged once in LDS, filters in registers (conv_s2.hip)
+            HaloArgs h; memset(&h, 0, sizeof h);
+            const TView in = view_of(c, L.in[0]);
+            h.in = a.in; h.in_stride = a.in_stride; h.w = a.wt; h.b = a.bias; h.Kpad = a.Kpad; h.Cin = L.cin; h.Cout = L.filters; h.act = L.act;
+            h.res = a.res; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = in.h; h.W = in.w; h.dt = L.in_dt;
+            if (conv_s2_ok(h)) { HIPCK(c, launch_conv_s2(h, s)); break; }
+        }
         if (a.split) {
             int cfg = L.tile_cfg >= 0 && conv_cfg_split_ok(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
             if (conv_cfg_is_halo(cfg) && (!conv_halo_cfg_ok(a, cfg) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
