@@ -58,20 +58,29 @@ def cpu_baseline(cfg_txt, flat, budget_s=25.0):
             "sample": "%d x YOLOv3-416 batch-1 forward after 1 warm-up, median %.3f s/image" % (len(times), med)}
 
 
-def parity(eng, cfg_txt, flat, imgs_u8, size, thr=0.5, margin=1e-2):
-    """Boxes of the timed engine (its dtype, its tile plan) against the fp32 oracle (TF semantics) on the first images of the timed batch:
-    over every oracle candidate whose score clears `thr` by more than `margin` (a candidate inside the band may legitimately flip),
-    min IoU and max |dscore|.  The checker runs on the host outside the timed region; tests/test_gpu_tuned.py asserts the same measure
-    over all 32 images."""
+def oracle_boxes(cfg_txt, flat, imgs_u8, size, thr=0.5):
+    """fp32 oracle (TF semantics) on the given images: per image (boxes, scores, rows) of every candidate above `thr`.  Host, outside the timed region."""
     from oracle import yolo_ref as R
-    t0 = time.time()
-    det = eng.forward(imgs_u8)
-    osecs = R.parse_cfg(cfg_txt.replace("yolo_store=bf16\n", "").replace("yolo_store=fp8\n", "")); params = R.unflatten_weights(flat, osecs)
-    miou, mds, cnt, lost = 1.0, 0.0, 0, 0
+    osecs = R.parse_cfg(cfg_txt); params = R.unflatten_weights(flat, osecs)
+    refs = []
     for b in range(imgs_u8.shape[0]):
         heads, _ = R.forward(osecs, params, imgs_u8[b:b + 1].astype(np.float32) / np.float32(255))
         ref = R.yolo_v3_detections(heads, size, ratio=True)[0]
         rb, rs, rc, ridx = R.select_threshold(ref, thr)
+        refs.append((rb, rs, ridx))
+    return refs
+
+
+def parity(eng, refs, imgs_u8, thr=0.5, margin=1e-2, t_oracle=0.0):
+    """Boxes of the timed engine (its dtype, its tile plan) against the fp32 oracle (TF semantics) on the first images of the timed batch:
+    over every oracle candidate whose score clears `thr` by more than `margin` (a candidate inside the band may legitimately flip),
+    min IoU and max |dscore|.  The checker runs on the host outside the timed region; tests/test_gpu_tuned.py asserts the same measure
+    over all 32 images."""
+    t0 = time.time()
+    det = eng.forward(imgs_u8)
+    miou, mds, cnt, lost = 1.0, 0.0, 0, 0
+    for b in range(imgs_u8.shape[0]):
+        rb, rs, ridx = refs[b]
         ok = rs >= thr + margin
         if not ok.any():
             continue
@@ -84,8 +93,60 @@ def parity(eng, cfg_txt, flat, imgs_u8, size, thr=0.5, margin=1e-2):
         iou = inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1]) - inter + 1e-12)
         miou = min(miou, float(iou.min())); mds = max(mds, float(np.abs(rs[ok] - sc).max())); cnt += int(ok.sum()); lost += int((sc <= thr).sum())
     return {"min_iou": round(miou, 5), "max_dscore": round(mds, 5), "candidates": cnt, "lost": lost, "images": int(imgs_u8.shape[0]),
+            "meets_north_star_iou_0p999": bool(miou >= 0.999 and lost == 0),
             "reference": "fp32 oracle (oracle/yolo_ref.py, TF semantics)", "weights": "seeded synthetic darknet stream (seed 0), benign batch-norm statistics",
-            "threshold": thr, "margin": margin, "seconds": round(time.time() - t0, 1)}
+            "threshold": thr, "margin": margin, "seconds": round(time.time() - t0 + t_oracle, 1)}
+
+
+def tolerance_line(hip, IO, base_cfg_txt, flat, args, dev, stream, images, refs, imgs_par, kind):
+    """The configuration that MEETS north_star's tolerance (decoded boxes within IoU >= 0.999 of the fp32 reference), timed in the same process
+    on the same resident batch, after and outside the headline's timed region.  bf16 -- BASELINE's named type, the
+    headline -- has an 8-bit significand and cannot hold 0.999 (1 - IoU falls 4-5 x per 2 bits, 0.999 needs 13-17); this
+    leg is the fastest configuration of the library that does on every weight flavour of tests/test_gpu_tolerance.py: split-fp16 pairs
+    (22 significant bits, W_hi x_hi + W_hi x_lo + W_lo x_hi on the fp16 MFMA = 3 MFMA products per algorithmic product, fp32 accumulation).
+    Same step (uint8 batch resident in HBM -> conv stack -> decode -> threshold -> TF-NMS), same graph replay, same event timing."""
+    import torch
+    from yolo_tensorflow_amd import dist as ydist
+    B = int(images.shape[0]); max_out = 20
+    cfg_txt = base_cfg_txt; products = 3.0; what = "split fp16 pairs (hi + lo) on every tensor and filter"
+    eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP16X2, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO, device=dev.index, stream=stream.cuda_stream)
+    try:
+        eng.set_weights(flat)
+        eng.forward(images, want_detections=False)
+        tuned = os.path.join(ROOT, "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (args.size, B, kind))
+        loaded = False
+        if os.path.exists(tuned):
+            plan = json.load(open(tuned))
+            if plan.get("num_cfgs") == hip.op_conv_num_cfgs() and len(plan["cfgs"]) == eng.num_layers:
+                eng.set_tile_configs(plan["cfgs"]); loaded = True
+        rec, boxes, counts = ydist.alloc_flat_records(B, max_out, dev)
+
+        def step():
+            eng.detect_graph(images, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=max_out, nms_mode=hip.NMS_TF, select_mode=hip.SELECT_GT)
+        for _ in range(max(3, args.warmup)):
+            step()
+        steps = max(5, min(args.steps, 50))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        total_ms, conv_ms = eng.time_forward(B, 5, conv=True)
+        flops = eng.conv_flops() * B
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        out = {"dtype": kind, "what": what, "value": round(B * steps / elapsed, 2), "unit": "img/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+               "tile_plan": os.path.basename(tuned) if loaded else "built-in",
+               "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                            "mfma_products": products, "mfma_tflops": round(achieved * products, 2), "mfma_frac": round(achieved * products / PEAK_BF16_TFLOPS, 4),
+                            "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4),
+                            "note": "achieved / frac count the ALGORITHMIC FLOPs (the reference's formula); mfma_* the products the matrix pipe executes"},
+               "tolerance": "north_star: decoded boxes within IoU >= 0.999 of the fp32 reference on identical inputs"}
+        if refs is not None:
+            out["parity"] = parity(eng, refs, imgs_par)
+        return out
+    finally:
+        eng.close()
 
 
 def latency_b1(hip, cfg_txt, flat, args, dev, stream, fp8, fp32, fp16, x2, eng1=None, iters=200):
@@ -149,6 +210,10 @@ def main():
                          "; mixed16 is the split-fp16 network with pairs only on the first layers (tuned/yolov3_*_mixed16.json: where rounding noise is amplified most), "
                          "plain fp16 and the fp16 configuration's fused kernels after them "
                          "(each reported as a separate line)")
+    ap.add_argument("--tolerance", choices=("fp16x2", "none"), default="fp16x2",
+                    help="after the headline leg, time the configuration that meets north_star's IoU >= 0.999 in the same process and print it inside the "
+                         "same JSON line as `tolerance_line` (rank 0, N = 1, default workload only; outside the headline's timed region)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip roofline.calib_tflops / clock_ghz (the register-resident MFMA yardstick, 0.4 s)")
     args = ap.parse_args()
     if args.config4:
         args.size, args.global_batch = 608, args.global_batch or 64
@@ -318,8 +383,24 @@ def main():
                                          "regime": "launch-bound (per-launch fixed cost dominates: DESIGN.md section 6)" if achieved / peak < 0.25 else "matrix-pipe / fixed-cost mix"}
         if G == 1 and not args.no_latency:
             out.update(latency_b1(hip, cfg_txt, flat, args, dev, stream, fp8, fp32, fp16, x2, eng if B == 1 else None))
+        if not args.no_calibration and not fp32:
+            # the box's own yardstick, outside the timed region and AFTER the timed work (the chip is warm): what a register-resident MFMA loop
+            # sustains here and at which clock -- `frac_of_calib` is what compares between boxes (the same binary reads 9 % apart by box)
+            ct, cg = hip.calibrate(0.4, f16=fp16 or x2, device=local_rank, stream=stream.cuda_stream)
+            mult = 2.0 if fp8 and not mixed else 1.0          # (the e4m3 MFMA runs at twice the 16-bit rate the loop measures)
+            out["roofline"].update({"calib_tflops": round(ct, 1), "clock_ghz": round(cg, 3),
+                                    "frac_of_calib": round(achieved / (ct * mult), 4) if ct > 0 and not mixed else None,
+                                    "calib": "yolo_calibrate: register-resident v_mfma_f32_16x16x32 loop, 8 waves per CU, random operands, 0.4 s; clock = s_memtime / s_memrealtime"})
+        refs, imgs_par, t_or = None, None, 0.0
         if G == 1 and args.parity_images > 0:
-            out["parity"] = parity(eng, cfg_txt, flat, images[:min(args.parity_images, n_local)].cpu().numpy(), args.size)
+            imgs_par = images[:min(args.parity_images, n_local)].cpu().numpy()
+            t_or = time.time()
+            refs = oracle_boxes(cfg_txt.replace("yolo_store=bf16\n", "").replace("yolo_store=fp8\n", "").replace("yolo_pair=0\n", "").replace("yolo_pair=1\n", "").replace("yolo_pair_input=0\n", ""), flat, imgs_par, args.size)
+            t_or = time.time() - t_or
+            out["parity"] = parity(eng, refs, imgs_par, t_oracle=t_or)
+        if G == 1 and args.tolerance != "none" and args.dtype == "bf16" and not strong and not args.no_graph:
+            base_txt = IO.cfg_text("yolov3") if args.size == 416 else IO.with_input_size(IO.cfg_text("yolov3"), args.size)
+            out["tolerance_line"] = tolerance_line(hip, IO, base_txt, flat, args, dev, stream, images, refs, imgs_par, args.tolerance)
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_txt, flat)
         print(json.dumps(out), flush=True)

@@ -45,7 +45,10 @@ int yolo_dist_unique_id(uint8_t id[128]);
  * the caller's own `comm` (an ncclComm_t made on ctx's device; the caller keeps ownership), or, when
  * comm is NULL, one initialised here from `id` (ncclCommInitRank: collective over all ranks, destroyed
  * by yolo_dist_destroy).  Allocates the record buffer, the gather buffer and a pinned host mirror.
- * On failure returns NULL and writes a message to err. */
+ * On failure returns NULL and writes a message to err.  The communicator is joined before anything is
+ * allocated, so a rank that fails locally does not leave the others inside ncclCommInitRank.
+ * Life time: destroy the yolo_dist BEFORE its context (a step uses the context; yolo_dist_destroy itself
+ * only needs the device number, which it keeps). */
 yolo_dist *yolo_dist_create(yolo_ctx *ctx, int world_size, int rank, const uint8_t id[128], void *comm,
                             int global_batch, int max_out, char *err, size_t err_len);
 

@@ -227,6 +227,11 @@ int yolo_layer_output(yolo_ctx *ctx, int index, int n, float *out, size_t out_fl
  * was given a device-resident uint8 batch, the fused first layers read the caller's buffer in place: it must still be valid here.  A
  * timing pass over more images than that batch held reads the context's own (zero-initialised or previously staged) input instead. */
 int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *conv_ms);
+/* What this chip sustains on a register-resident MFMA loop (v_mfma_f32_16x16x32_bf16, or _f16 when f16 != 0; random operands, 8 waves per
+ * CU, back-to-back launches for `seconds`, the second half measured): TFLOP/s and the shader clock the waves held (GHz; s_memtime over
+ * s_memrealtime).  bench.py prints both next to its roofline fraction: the same binary reads 9 % apart by box, and `frac / (tflops / peak)`
+ * is what compares across boxes.  No counterpart in the reference.  stream: a hipStream_t or NULL. */
+int yolo_calibrate(int device, void *stream, int f16, double seconds, float *tflops, float *clock_ghz);
 /* Per-layer kernel time (ms, averaged over iters) for batch n into ms_out[num_layers]. */
 int yolo_time_layers(yolo_ctx *ctx, int n, int iters, float *ms_out);
 /* Tries every conv tile configuration on every conv layer at batch n and keeps the fastest. */

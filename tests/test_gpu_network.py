@@ -685,3 +685,61 @@ def test_head_as_the_tail_of_its_3x3_equals_the_separate_launch(hiplib, dtype_na
     with pytest.raises(hiplib.YoloError):
         eng.set_tile_configs(bad)
     eng.close()
+
+
+def _with_classes(txt, classes):
+    """yolov3 cfg text with another class count: `classes=` of every [yolo] section and the filter count of the head conv in front of it."""
+    out = []; secs = txt.split("[")
+    for k, sec in enumerate(secs):
+        if sec.startswith("yolo]"):
+            sec = "\n".join(("classes=%d" % classes) if l.split("=")[0].strip() == "classes" else l for l in sec.split("\n"))
+            prev = out[-1].split("\n")
+            out[-1] = "\n".join(("filters=%d" % (3 * (5 + classes))) if l.split("=")[0].strip() == "filters" else l for l in prev)
+        out.append(sec)
+    return "[".join(out)
+
+
+@pytest.mark.parametrize("classes", [20, 1])
+def test_head_tail_with_few_filters_reads_inside_its_fragment_image(hiplib, classes):
+    """a detection head fused as the tail of its 3x3 is read by all eight waves, 32 filter rows each, whatever its filter count --
+    a VOC head (75 filters) or a 1-class head (18) used to get a fragment image of roundup(filters, 16) rows and was read past its end.
+    The image is now the padded 256 rows: the fused plan equals the plan that launches the head, bit for bit, at both class counts."""
+    txt = _with_classes(IO.cfg_text("yolov3"), classes)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=33)
+    img = np.random.default_rng(34).integers(0, 256, (2, 416, 416, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.BF16)
+    eng.set_weights(flat)
+    plain = eng.get_tile_configs().copy(); plain = np.where(plain >= 10000, plain - 10000, plain)
+    eng.set_tile_configs(plain)
+    want = eng.forward(img); want_raw = eng.head_raw(2, 2)
+    assert want.shape[-1] == 5 + classes
+    layer = [i for i, s in enumerate(secs[1:]) if s["type"] == "yolo"][2] - 2
+    trial = plain.copy(); trial[layer] = 10000 + 40
+    eng.set_tile_configs(trial)
+    assert np.array_equal(eng.forward(img), want)
+    assert np.array_equal(eng.head_raw(2, 2), want_raw)
+    eng.close()
+
+
+def test_tail_flag_on_a_fixed_kernel_is_refused(hiplib):
+    """the window-staged stride-2 layer (and every other fixed kernel: stem, conv3, fused blocks) hosts no 1x1 tail -- its launch
+    ignores the tail's arguments, so a plan carrying `cfg + 10000` there would silently skip the 1x1 conv.  The planner no longer offers it
+    as a producer and yolo_set_tile_configs refuses the flag; at 320 x 320 (where the following 1x1 is NOT absorbed by a fused block) the
+    network still equals the oracle-checked layer-by-layer plan."""
+    for size in (416, 320):
+        txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+        eng = hiplib.Engine(txt, max_batch=1, dtype=hiplib.BF16)
+        eng.set_weights(IO.synth_weights(IO.parse_cfg(txt), seed=35))
+        cfgs = eng.get_tile_configs().copy()
+        bad = cfgs.copy(); bad[5] = 10000 + 36              # cfg layer 5: 3x3 / stride 2, 64 -> 128
+        with pytest.raises(hiplib.YoloError):
+            eng.set_tile_configs(bad)
+        eng.close()
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), 320)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=35)
+    img = np.random.default_rng(36).integers(0, 256, (1, 320, 320, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=1, dtype=hiplib.BF16); eng.set_weights(flat)
+    got = eng.forward(img); eng.close()
+    ref = hiplib.Engine(txt, max_batch=1, dtype=hiplib.BF16, keep_layers=True); ref.set_weights(flat)
+    want = ref.forward(img); ref.close()
+    assert np.array_equal(got, want)

@@ -8,9 +8,11 @@ SRC=$HERE/yolo_tensorflow_amd/csrc
 OBJ=/tmp/abbuild/$NAME; mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $*"
 pids=()
-for f in conv_igemm conv_halo13 conv_stem conv_block conv_block64 conv_f32; do /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o & pids+=($!); done
-for f in ew_ops post_ops; do /opt/rocm/bin/hipcc $FLAGS -ffp-contract=off -c $SRC/$f.hip -o $OBJ/$f.o & pids+=($!); done
-for f in yolo_api yolo_plan yolo_pack yolo_run yolo_ops yolo_dist; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $SRC/$f.cpp -o $OBJ/$f.o & pids+=($!); done
+# every source of the library, as buildinfo.source_hash and the Makefile see them (a hand-kept list went stale: ADVICE r05)
+for src in $SRC/*.hip; do f=$(basename $src .hip)
+  case $f in ew_ops|post_ops) X="-ffp-contract=off";; *) X="";; esac
+  /opt/rocm/bin/hipcc $FLAGS $X -c $src -o $OBJ/$f.o & pids+=($!); done
+for src in $SRC/yolo_*.cpp; do f=$(basename $src .cpp); /opt/rocm/bin/hipcc $FLAGS -x hip -c $src -o $OBJ/$f.o & pids+=($!); done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $HERE/tools/probe/ab/lib_$NAME.bin $OBJ/*.o -ldl
 ls -la $HERE/tools/probe/ab/lib_$NAME.bin

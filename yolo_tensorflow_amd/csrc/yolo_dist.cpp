@@ -62,6 +62,7 @@ constexpr int kNcclInt32 = 2;
 
 struct yolo_dist {
     yolo_ctx *ctx = nullptr;
+    int device = 0;                  // cached: yolo_dist_destroy must not look into a context the caller may already have destroyed
     int world = 1, rank = 0, global_batch = 0, max_out = 0, per = 0, first = 0, count = 0;
     Comm comm = nullptr; bool own_comm = false;
     int32_t *d_rec = nullptr, *d_all = nullptr, *h_all = nullptr;      // [flat], [world][flat] device; [world][flat] pinned host
@@ -126,20 +127,22 @@ yolo_dist *yolo_dist_create(yolo_ctx *ctx, int world_size, int rank, const uint8
     if (!r.so) return bad(eb, "yolo_dist_create: %s", r.why.c_str());
     if (hipSetDevice(ctx->device) != hipSuccess) return bad(eb, "yolo_dist_create: hipSetDevice(%d) failed", ctx->device);
     yolo_dist *d = new yolo_dist;
-    d->ctx = ctx; d->world = world_size; d->rank = rank; d->global_batch = global_batch; d->max_out = max_out;
+    d->ctx = ctx; d->device = ctx->device; d->world = world_size; d->rank = rank; d->global_batch = global_batch; d->max_out = max_out;
     d->per = per; d->first = first; d->count = count; d->flat = yolo_dist_flat_words(per, max_out);
-    const size_t bytes = d->flat * sizeof(int32_t);
-    // the record buffer is zeroed once: the padding rows of a short rank (count < per) are never written and travel as zeros
-    if (hipMalloc((void **)&d->d_rec, bytes) != hipSuccess || hipMemset(d->d_rec, 0, bytes) != hipSuccess ||
-        hipMalloc((void **)&d->d_all, bytes * world_size) != hipSuccess || hipHostMalloc((void **)&d->h_all, bytes * world_size) != hipSuccess) {
-        (void)hipGetLastError(); yolo_dist_destroy(d); return bad(eb, "yolo_dist_create: out of memory (%zu bytes x %d ranks)", bytes, world_size);
-    }
+    // The communicator FIRST: ncclCommInitRank is collective, and a rank that returned on a failed allocation before joining it would leave
+    // the others waiting in theirs.
     if (comm) d->comm = comm;
     else {
         UniqueId u; memcpy(u.internal, id, 128);
         const int e = r.CommInitRank(&d->comm, world_size, u, rank);
         if (e != 0) { d->comm = nullptr; const char *s = r.GetErrorString(e); yolo_dist_destroy(d); return bad(eb, "ncclCommInitRank: %s", s ? s : "?"); }
         d->own_comm = true;
+    }
+    const size_t bytes = d->flat * sizeof(int32_t);
+    // the record buffer is zeroed once: the padding rows of a short rank (count < per) are never written and travel as zeros
+    if (hipMalloc((void **)&d->d_rec, bytes) != hipSuccess || hipMemset(d->d_rec, 0, bytes) != hipSuccess ||
+        hipMalloc((void **)&d->d_all, bytes * world_size) != hipSuccess || hipHostMalloc((void **)&d->h_all, bytes * world_size) != hipSuccess) {
+        (void)hipGetLastError(); yolo_dist_destroy(d); return bad(eb, "yolo_dist_create: out of memory (%zu bytes x %d ranks)", bytes, world_size);
     }
     return d;
 }
@@ -150,13 +153,19 @@ int yolo_dist_detect_async(yolo_dist *d, const void *images, int fmt, float scal
     if (!d || !d->ctx) return YOLO_ERR_INVALID;
     yolo_ctx *c = d->ctx;
     HIPCK(c, hipSetDevice(c->device));
+    // A rank whose LOCAL step fails still joins the exchange (its records zeroed: counts 0), and reports the failure afterwards: leaving a
+    // collective early would hang every other rank.
+    int local = YOLO_OK;
     if (d->count > 0) {
-        if (!images) return fail(c, YOLO_ERR_INVALID, "yolo_dist_detect: no images for this rank's %d-image slice", d->count);
         yolo_box *boxes = (yolo_box *)d->d_rec;
         int32_t *counts = d->d_rec + (size_t)d->per * d->max_out * kRecordWords;
-        if (int r = yolo_detect_graph(c, images, d->count, fmt, scale, score_thr, iou_thr, d->max_out, nms_mode, select_mode, boxes, counts)) return r;
+        if (!images) local = fail(c, YOLO_ERR_INVALID, "yolo_dist_detect: no images for this rank's %d-image slice", d->count);
+        else local = yolo_detect_graph(c, images, d->count, fmt, scale, score_thr, iou_thr, d->max_out, nms_mode, select_mode, boxes, counts);
+        if (local != YOLO_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(d->d_rec, 0, d->flat * sizeof(int32_t), c->stream); }
     }
+    const std::string local_msg = local != YOLO_OK ? std::string(yolo_last_error(c)) : std::string();
     const int e = rccl().AllGather(d->d_rec, d->d_all, d->flat, kNcclInt32, d->comm, c->stream);
+    if (local != YOLO_OK) return fail(c, local, "%s (this rank joined the exchange with zero records)", local_msg.c_str());
     if (e != 0) { const char *s = rccl().GetErrorString(e); return fail(c, YOLO_ERR_HIP, "ncclAllGather: %s", s ? s : "?"); }
     if (gathered_dev) *gathered_dev = d->d_all;
     return YOLO_OK;
@@ -177,7 +186,7 @@ int yolo_dist_detect(yolo_dist *d, const void *images, int fmt, float scale, flo
 void yolo_dist_destroy(yolo_dist *d)
 {
     if (!d) return;
-    if (d->ctx) (void)hipSetDevice(d->ctx->device);
+    (void)hipSetDevice(d->device);
     if (d->own_comm && d->comm && rccl().so) rccl().CommDestroy(d->comm);
     if (d->d_rec) (void)hipFree(d->d_rec);
     if (d->d_all) (void)hipFree(d->d_all);

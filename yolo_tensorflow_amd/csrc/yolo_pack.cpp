@@ -156,9 +156,12 @@ int tail_fragments(yolo_ctx *c)
     for (auto &T : c->layers) {
         if (T.type != L_CONV || T.fused_into < 0) continue;
         if (T.in_dt != DT_BF16 && T.in_dt != DT_F16) continue;          // (16-bit tails only; also the bf16 islands of a mixed e4m3 plan)
-        const int C2 = roundup(T.filters, 16), K = T.kpad;           // K == the producer's channel count, a multiple of 32 (a head's 255 filters: 256 rows, the last one zero)
-        if (C2 > T.cout_pad || K % 32) continue;
-        src.resize((size_t)T.cout_pad * K); dst.resize((size_t)C2 * K);
+        // K == the producer's channel count, a multiple of 32.  A HEAD tail is read by all eight waves, 32 rows each, whatever its filter count
+        // (conv_igemm_kernel.h, head mode: t2g = wave_id): its fragment image is always the padded 256 rows, the rows past the filters zero
+        // (18 filters of a 1-class head, 75 of a VOC head: ADVICE r05 -- the short image was read past its end).
+        const int C2 = T.head ? T.cout_pad : roundup(T.filters, 16), K = T.kpad;
+        if (C2 > T.cout_pad || K % 32 || (T.head && T.cout_pad < 256)) continue;
+        src.resize((size_t)T.cout_pad * K); dst.assign((size_t)C2 * K, 0);
         HIPCK(c, hipMemcpy(src.data(), T.d_w, src.size() * 2, hipMemcpyDeviceToHost));
         const int K2S = K / 32;
         for (int ct2 = 0; ct2 < C2 / 16; ++ct2)

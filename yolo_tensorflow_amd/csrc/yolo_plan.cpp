@@ -274,7 +274,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     if (ctx16 && !c->keep_layers && !getenv("YOLO_NO_TAIL")) {
         for (int i = 0; i + 1 < NL; ++i) {
             Layer &P = c->layers[i];
-            if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || P.blk || (P.filters != 128 && P.filters != 256)) continue;
+            if (P.type != L_CONV || P.fc || P.head || P.stem || P.stem_skip || P.stem_tail || P.blk || P.s2 || P.halo || (P.filters != 128 && P.filters != 256)) continue;      // (fixed kernels host no tail: run_layer would skip the 1x1)
             if (c->split() && (P.pair || c->pair_of(P.in[0]))) continue;       // (split-fp16 networks: the tail rides on plain fp16 layers only)
             int o = i;
             if (P.residual_from >= -1) o = i + 1;            // its shortcut was folded into it: consumers read layer i+1

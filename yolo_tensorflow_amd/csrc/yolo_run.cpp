@@ -657,6 +657,7 @@ int yolo_set_tile_configs(yolo_ctx *c, const int32_t *cfgs)
         if (v != -1 && v != CONV_CFG_DIRECT && (v < 0 || v >= conv_num_cfgs())) return fail(c, YOLO_ERR_INVALID, "layer %zu: tile config %d out of range", i, v);
         if (tail && (c->layers[i].tail_layer < 0 || !conv_cfg_tail_ok(v, c->layers[i].filters, c->layers[i].in_dt == DT_FP8, c->layers[c->layers[i].tail_layer].head) || c->layers[c->layers[i].tail_layer].in_dt != c->layers[i].in_dt))
             return fail(c, YOLO_ERR_INVALID, "layer %zu: plan asks for a fused 1x1 tail this layer / tile config cannot run", i);
+        if (tail && fixed_kernel(c->layers[i])) return fail(c, YOLO_ERR_INVALID, "layer %zu runs a fixed kernel (stem / conv3 / block / stride-2): it hosts no fused 1x1 tail", i);
         if (tail && conv_cfg_is_halo(v)) {
             ConvArgs a = conv_args(c, c->layers[i], c->max_batch);
             if (!conv_halo_cfg_ok(a, v)) return fail(c, YOLO_ERR_INVALID, "layer %zu: the halo-staged tile config %d does not apply to this layer, so it cannot carry the fused 1x1 tail", i, v);

@@ -340,7 +340,11 @@ def bn_real_vectors(secs, path=None):
     import os
     convs = [s for s in secs[1:] if s["type"] == "convolutional"]
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
-    for name in ([path] if path else [os.path.join(golden, "yolov3_bn_real.npz"), os.path.join(golden, "yolov2_bn_real.npz")]):
+    names = [path] if path else [os.path.join(golden, "yolov3_bn_real.npz"), os.path.join(golden, "yolov2_bn_real.npz")]
+    missing = [n for n in names if not os.path.exists(n)]
+    if len(missing) == len(names):      # a test-only generator: the fixtures live in the source tree's tests/golden/, not in an installed package
+        raise FileNotFoundError("the real batch-norm vectors are test fixtures (%s): not found -- run from the source tree or pass path=" % ", ".join(missing))
+    for name in names:
         if not os.path.exists(name):
             continue
         z = np.load(name)

@@ -33,7 +33,7 @@ EXPORTS = [
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_darknet_boxes", "yolo_last_layer_size", "yolo_last_layer_output", "yolo_op_letterbox",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
-    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw",
+    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw", "yolo_calibrate",
 ]
 # include/yolo_dist.h: the image-sharded detect step
 DIST_EXPORTS = ["yolo_shard_bounds", "yolo_dist_flat_words", "yolo_dist_split_records", "yolo_dist_unique_id", "yolo_dist_create",
@@ -109,6 +109,7 @@ def load_library():
     l.yolo_postprocess_rows.argtypes = [P, I, F, F, I, I, I, P, P, P, I]
     l.yolo_last_layer_output_batch.argtypes = [P, I, P, C.c_size_t]
     l.yolo_head_raw.argtypes = [P, I, I, P, C.c_size_t]
+    l.yolo_calibrate.argtypes = [I, P, I, C.c_double, FP, FP]
     l.yolo_shard_bounds.argtypes = [I, I, I, C.POINTER(I), C.POINTER(I)]
     l.yolo_dist_flat_words.argtypes = [I, I]; l.yolo_dist_flat_words.restype = C.c_size_t
     l.yolo_dist_split_records.argtypes = [P, I, I, I, P, P]
@@ -410,6 +411,14 @@ def op_conv_num_cfgs():
     return load_library().yolo_op_conv_num_cfgs()
 
 
+def calibrate(seconds=0.4, f16=False, device=0, stream=None):
+    """yolo_calibrate: (TFLOP/s, GHz) this chip sustains on a register-resident MFMA loop (bf16, or fp16 with f16=True) -- the yardstick
+    bench.py prints next to its roofline fraction so that lines measured on different boxes can be normalised."""
+    t, g = C.c_float(0), C.c_float(0)
+    _op_check(load_library().yolo_calibrate(device, _stream_handle(stream), 1 if f16 else 0, float(seconds), C.byref(t), C.byref(g)), "yolo_calibrate")
+    return float(t.value), float(g.value)
+
+
 def op_upsample2x(x, semantics=SEM_TF, device=0):
     x = _f32(x); n, h, w, c = x.shape
     out = np.empty((n, 2 * h, 2 * w, c), dtype=np.float32)
@@ -545,6 +554,14 @@ class ShardedDetector(object):
         return [boxes[i, :counts[i]].copy() for i in range(self.global_batch)]
 
     def close(self):
+        """Destroy BEFORE the engine (include/yolo_dist.h): a later step would use a dead context.  (yolo_dist_destroy itself only needs the
+        device number, which the handle keeps, so the order of two close() calls cannot crash.)"""
         if self.h:
             self.lib.yolo_dist_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
