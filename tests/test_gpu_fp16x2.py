@@ -17,7 +17,7 @@ from test_gpu_tuned import box_deviation
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.abspath(__file__))
-SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 25, 26, 27, 28, 33, 34, 45, 49, 52)
+SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 33, 34, 45, 49, 52)       # (round 6: the pair K loop needs 128-byte rows -- one 32-channel group hi | lo)
 SPLIT_HALO = (40, 41, 43)
 
 
@@ -51,7 +51,7 @@ def test_conv_fp16x2_vs_emulation_and_tile_shapes(hiplib, shape):
         # far closer to the exact fp32 conv than plain fp16 storage
         exact = R.conv2d_nhwc(x, w, st) + b; exact = np.where(exact > 0, exact, 0.1 * exact) + (r if r is not None else 0)
         assert np.abs(got - exact).max() <= 2e-5 * np.abs(exact).max()
-        for cfg in SPLIT_CFGS + (SPLIT_HALO if (k == 3 and st == 1 and h % 13 == 0 and cin % 64 == 0) else ()):
+        for cfg in SPLIT_CFGS + (SPLIT_HALO if (k == 3 and st == 1 and h % 13 == 0 and cin % 32 == 0) else ()):
             assert np.array_equal(hiplib.op_conv2d(x, w, b, stride=st, act=1, residual=r, dtype=hiplib.FP16X2, tile_cfg=cfg), got), (shape, cfg)
         if r is not None:       # the shortcut folded into the conv's epilogue == the separate k_add_split launch, bit for bit
             os.environ["YOLO_SPLIT_UNFUSED"] = "1"
@@ -171,9 +171,10 @@ def test_fp16x2_refuses_what_it_does_not_serve(hiplib):
     with pytest.raises(hiplib.YoloError, match="split-fp16"):
         hiplib.Engine(IO.cfg_text("yolov1"), dtype=hiplib.FP16X2)
     # a max_batch whose whole-batch activation window passes the conv kernels' 32-bit offsets is refused at yolo_create with the
-    # number that does fit (a split tensor is 3 x as wide: 416 x 416 stops at 64 images), not at the first forward with a bare 'invalid value'
-    with pytest.raises(hiplib.YoloError, match=r"at most 6\d images"):
-        hiplib.Engine(IO.cfg_text("yolov3"), max_batch=70, dtype=hiplib.FP16X2)
+    # number that does fit (a pair tensor is 2 x as wide since round 6 -- interleaved hi | lo, no duplicate hi block: 416 x 416 stops at 96
+    # images, 64 before), not at the first forward with a bare 'invalid value'
+    with pytest.raises(hiplib.YoloError, match=r"at most 9\d images"):
+        hiplib.Engine(IO.cfg_text("yolov3"), max_batch=100, dtype=hiplib.FP16X2)
 
 
 # ---- mixed plans (round 5): pairs on some tensors, plain fp16 on the rest (cfg keys yolo_pair / yolo_pair_input) ----

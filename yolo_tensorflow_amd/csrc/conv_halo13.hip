@@ -12,6 +12,7 @@ bool conv_halo_cfg_ok(const ConvArgs &a, int cfg)
 {
     int bh, bw; halo_cfg_block(cfg, bh, bw);
     if (bh != HALO_B && (a.in_dt == DT_FP8 || a.split)) return false;      // the rectangular blocks are instantiated for bf16 / fp16 storage
+    if (a.pairk && !(a.split && (cfg == 40 || cfg == 41 || cfg == 43))) return false;      // pair K loop: the free-running forms writing pairs
     return halo_ok(a, bh, bw);
 }
 static bool halo_ok(const ConvArgs &a, int bh, int bw)
@@ -30,7 +31,7 @@ static bool halo_ok(const ConvArgs &a, int bh, int bw)
     return (double)a.N * a.H * a.W * a.in_stride * dt_size(a.in_dt) < 2147483648.0;
 }
 
-template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false>
+template <int WC, int TC, int NL, int EB, bool FREE = false, int NS = 2, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false, bool PAIRK = false>
 static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
 {
     if (a.tail_f32 && !HEADT) return hipErrorInvalidValue;        // a head as the tail runs on the HEADT instantiations (tile configurations 40 and 54)
@@ -39,9 +40,9 @@ static hipError_t launch_h(const ConvArgs &a, hipStream_t s)
     const long tiles = blocks * ((a.Cout + BC - 1) / BC);
     constexpr size_t lds = conv_lds_bytes<WP, WC, TP, TC, NS, BK, NL, true, BH, BW>();
     static_assert(lds <= 160 * 1024, "halo form: LDS");
-    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT>, lds);
+    hipError_t e = conv_opt_in_lds((const void *)conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT, PAIRK>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, BH, BW));
+    hipLaunchKernelGGL((conv_igemm<WP, WC, TP, TC, NS, BK, true, NL, false, EB, true, FREE, H16, SPLIT, BH, BW, HEADT, PAIRK>), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(64 * (WP * WC + NL)), lds, s, conv_tile_magic(a, BC, BH, BW));
     return hipGetLastError();
 }
 
@@ -83,7 +84,14 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
     }
     if (a.split) {        // split fp16 storage (YOLO_FP16X2): the free-running forms with the two-pass epilogue
         if (a.in_dt != DT_F16 || a.out_dt != DT_F16 || a.w2) return hipErrorInvalidValue;
-        switch (cfg) {
+        if (a.pairk)          // pairs in, pairs out: the pair K loop (three products per K-step row pair)
+            switch (cfg) {
+            case 40: return launch_h<8, 2, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
+            case 41: return launch_h<8, 1, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
+            case 43: return launch_h<8, 1, 0, 2, true, 3, true, true, HALO_B, HALO_B, false, true>(a, s);
+            default: return hipErrorInvalidValue;
+            }
+        switch (cfg) {          // plain fp16 in, pairs out (mixed plans)
         case 40: return launch_h<8, 2, 0, 2, true, 2, true, true>(a, s);
         case 41: return launch_h<8, 1, 0, 2, true, 2, true, true>(a, s);
         case 43: return launch_h<8, 1, 0, 2, true, 3, true, true>(a, s);

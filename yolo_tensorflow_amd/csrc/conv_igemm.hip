@@ -295,9 +295,10 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     // (16-bit storage: bf16, or fp16 -- the same tile table, the same kernels with the other MFMA and conversions)
     if (a.in_dt != DT_BF16 && a.in_dt != DT_F16) return hipErrorInvalidValue;
     if (a.in_dt == DT_F16 && a.out_dt != DT_F16 && a.out_dt != DT_F32) return hipErrorInvalidValue;
+    if (a.pairk) return launch_conv_pair(a, cfg, s);          // the input is an interleaved pair tensor: the pair K loop (conv_pair.hip, conv_halo13.hip)
     if (a.split) {
-        // split fp16 storage (YOLO_FP16X2): fp16 operands, 16-bit outputs written as hi | lo | hi blocks (fp32 head outputs as ever); a
-        // subset of the tile table is instantiated
+        // split fp16 storage (YOLO_FP16X2), PLAIN input (or the network input's three blocks): fp16 operands, the ordinary K loop, 16-bit
+        // outputs written as interleaved pairs (fp32 head outputs as ever); a subset of the tile table is instantiated
         if (a.in_dt != DT_F16 || (a.out_dt != DT_F16 && a.out_dt != DT_F32) || a.w2 || (a.res && a.out_dt == DT_F32)) return hipErrorInvalidValue;
         switch (cfg) {
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_t<wp, wc, tp, tc, ns, bk, nl, 2, true, true>(a, s);

@@ -159,11 +159,17 @@ constexpr bool halo_div_ok(int bw) { for (unsigned r = 0; r < 256; ++r) if (((r 
 // 27 % fewer LDS bytes per FLOP -- was bit-identical and ran the 26x26 K-step in 0.99 us, the same as the 176 x 32 forms: every
 // variant lands on ~1.45 PFLOP/s, the rate the chip sustains on random bf16 operands once its clock management has reacted (the
 // CDNA4 guide's 'DVFS give-back': a cycle saved in an MFMA-dense main loop comes back partly as a lower clock).)
-// SPLIT (H16 only; YOLO_FP16X2): 16-bit outputs are stored as split fp16 pairs -- hi = f16(v) into channel blocks 0 and 2, lo = f16(v - hi)
-// into block 1 (blocks a.out_blk elements apart) -- by an epilogue of its own that stages the tile in LDS as fp32, half its channels at a time,
-// and folds the shortcut; the K loop is the ordinary fp16 one, run over the 3 x Cin 'channels' hi | lo | hi of the input against filter rows
-// W_hi | W_hi | W_lo (ew_ops.hip, split fp16 storage).
-template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false>
+// SPLIT (H16 only; YOLO_FP16X2): 16-bit outputs are stored as split fp16 pairs -- hi = f16(v), lo = f16(v - hi), interleaved per 32-channel
+// group (64 bytes of hi, 64 bytes of lo) -- by an epilogue of its own that stages the tile in LDS as fp32, half its channels at a time, and
+// folds the shortcut.  The K loop is PAIRK's when the input is such a tensor, the plain fp16 one when it is a plain tensor (mixed plans)
+// or the network input (hi | lo | hi blocks of its 8 padded channels against filter rows W_hi | W_hi | W_lo: rounds 4-5's form, kept there).
+// PAIRK (H16 only; round 6): the INPUT is a split-fp16 pair tensor in the interleaved layout -- per 32-channel group 64 bytes of hi followed by
+// 64 bytes of lo, i.e. one 128-byte K-step row [hi 32 | lo 32] of a pixel -- and the filter rows are packed the same way [W_hi 32 | W_lo 32].
+// Staging, LDS layout, swizzle and the halo tile are those of an fp16 conv over 2 x Cin 'channels'; what changes is the MFMA phase: per
+// K-step and accumulator tile THREE products, W_hi x_hi + W_lo x_hi + W_hi x_lo, from the same four fragment reads that feed two in the
+// plain loop.  (Rounds 4-5 stored hi | lo | hi against W_hi | W_hi | W_lo and ran the plain loop over 3 x Cin: 1.5 x the activation bytes,
+// LDS traffic, barriers and waits of this form for the same matrix work.)
+template <int WP, int WC, int TP, int TC, int NS, int BK, bool UNI, int NL = 0, bool DIAG = false, int EB = 2, bool HALO = false, bool FREE = false, bool H16 = false, bool SPLIT = false, int BH = HALO_B, int BW = HALO_B, bool HEADT = false, bool PAIRK = false>
 __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the stub of a
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     static_assert(EB == 2 || (EB == 1 && BK == 64), "fp8 operands need the 128-B-row form");
     static_assert(!H16 || EB == 2, "fp16 is a 16-bit storage type");
     static_assert(!SPLIT || (H16 && !DIAG), "split pairs are fp16 pairs");
+    static_assert(!PAIRK || (H16 && EB == 2 && BK == 64 && UNI && !DIAG && NL == 0), "pair K loop: fp16, 128-byte rows = one 32-channel group hi | lo, uniform taps");
     constexpr int RB = BK * 2;                 // bytes of one LDS tile row (one K-step of one pixel / filter)
     constexpr int EPC = 16 / EB;               // elements per 16-B chunk
     constexpr int BKE = RB / EB;               // K elements per step
@@ -521,6 +528,64 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
                 }
             }
+        } else if constexpr (PAIRK) {
+            // Pair K-step: the row's first K-half is hi, its second lo (activations and filters alike).  Per pixel sub-tile j three ops of TC
+            // MFMAs each: A_j = W_hi x_hi[j], B_j = W_lo x_hi[j], C_j = W_hi x_lo[j], all into acc[.][j].  They are issued skewed by one
+            // sub-tile -- step s: B_{s-1}, A_s, C_{s-1} -- so that two ops on the same accumulators are never adjacent (TC = 1 shapes would
+            // otherwise issue three dependent MFMAs back to back).  Fragments in order of first use: hi_0, hi_1, lo_0, hi_2, lo_1, ...,
+            // hi_{TP-1}, lo_{TP-2}, lo_{TP-1}; each is read PD first-uses ahead and pinned there, as in the plain loop.
+            if (is_consumer) {
+                constexpr int NF = 2 * TP;
+                constexpr int PD = NF < 4 ? NF : 4;
+                bf16x8 fwh[TC], fwl[TC], fx[NF];
+                auto rdf = [&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    constexpr bool lo = p == NF - 1 || (p >= 2 && p % 2 == 0);
+                    constexpr int j = p == 0 ? 0 : p == NF - 1 ? TP - 1 : lo ? p / 2 - 1 : (p + 1) / 2;
+                    fx[p] = *(const bf16x8 *)(xrow(j) + (lo ? xs1 : xs0));
+                };
+                auto first_use = [&](auto pc) {           // the op about to run uses fragment p for the first time: keep the read-ahead PD deep
+                    constexpr int p = decltype(pc)::value;
+                    if constexpr (p + PD < NF) rdf(std::integral_constant<int, p + PD>{});
+                };
+#pragma unroll
+                for (int i = 0; i < TC; ++i) { fwh[i] = *(const bf16x8 *)(wrow(i) + sw0); fwl[i] = *(const bf16x8 *)(wrow(i) + sw1); }
+                static_for<PD>([&](auto pc) { rdf(pc); });
+                static_for<TP + 1>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int pa = s == 0 ? 0 : 2 * s - 1;                        // hi_s
+                    constexpr int pb = s <= 1 ? 0 : 2 * (s - 1) - 1;                  // hi_{s-1}
+                    constexpr int pcx = s == TP ? NF - 1 : 2 * s;                      // lo_{s-1}
+                    if constexpr (s >= 1) {
+#pragma unroll
+                        for (int i = 0; i < TC; ++i) acc[i][s - 1] = mma16<true>(fwl[i], fx[pb], acc[i][s - 1]);
+                    }
+                    if constexpr (s < TP) {
+                        first_use(std::integral_constant<int, pa>{});
+#pragma unroll
+                        for (int i = 0; i < TC; ++i) acc[i][s] = mma16<true>(fwh[i], fx[pa], acc[i][s]);
+                    }
+                    if constexpr (s >= 1) {
+                        first_use(std::integral_constant<int, pcx>{});
+#pragma unroll
+                        for (int i = 0; i < TC; ++i) acc[i][s - 1] = mma16<true>(fwh[i], fx[pcx], acc[i][s - 1]);
+                    }
+                });
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + PD, 0);
+                static_for<TP + 1>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int pa = s == 0 ? 0 : 2 * s - 1, pcx = s == TP ? NF - 1 : 2 * s;
+                    if constexpr (s >= 1) __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                    if constexpr (s < TP) {
+                        if constexpr (pa + PD < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                    }
+                    if constexpr (s >= 1) {
+                        if constexpr (pcx + PD < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                    }
+                });
+            }
         } else if (is_consumer) {
             constexpr int KH = BK / 32;                 // K halves of 32 per step
             constexpr int NG = KH * TP;                 // MFMA groups per step
@@ -632,7 +697,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // everybody's have, and nobody reads the previous chunk's halo tile any more (the next chunk's pieces overwrite it)
             if constexpr (NS == 2) wait_vmcnt<0>(); else wait_vmcnt_rt<(NS - 2) * (LB + 1)>(NS == 3 ? f_ops1 : f_ops1 + f_ops2);
             block_barrier();
-            if (NC == 8 && wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * 32 / 64);      // half a K-step behind the SIMD's other wave (eight-wave forms: two waves per SIMD)
+            if (NC == 8 && wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * (PAIRK ? 48 : 32) / 64);      // half a K-step behind the SIMD's other wave (eight-wave forms: two waves per SIMD)
             s1 = stamp();
             issue();
             s2 = stamp();
@@ -724,17 +789,22 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
     };
     if (SPLIT && a.out_dt != DT_F32) {
         // ---- split fp16 pairs (YOLO_FP16X2): the tile goes through LDS as FP32, one half of its channels at a time (the same LDS footprint
-        //      as the 16-bit tile), and leaves as 16-byte pieces of eight channels: v -> hi = f16(v), lo = f16(v - hi) into blocks 0 / 1 / 2
-        //      (hi | lo | hi) of the pixel, `out_blk` elements apart.  A fused shortcut is exactly the separate launch's arithmetic
-        //      (k_add_split): the conv's own pair is formed first, then (f_hi + f_lo) + (x_hi + x_lo) in fp32, split again. ----
+        //      as the 16-bit tile), and leaves as 16-byte pieces of eight channels: v -> hi = f16(v), lo = f16(v - hi).  Round 6: the
+        //      INTERLEAVED pair layout -- channel c of a pixel has its hi at element (c / 32) * 64 + c % 32 and its lo 32 elements
+        //      (64 bytes) further, so that a 128-byte run of the pixel is one K-step row [hi 32 | lo 32] of the next conv (PAIRK) and a
+        //      concatenation of pair tensors is a channel window again.  Channels up to the next multiple of 32 are written (zeros: their
+        //      filter rows and biases are zero), the consumer reads whole groups.  A fused shortcut is exactly the separate launch's
+        //      arithmetic (k_add_split): the conv's own pair is formed first, then (f_hi + f_lo) + (x_hi + x_lo) in fp32, split again. ----
         if constexpr (SPLIT) {
         constexpr int HC = BC / 2, RS4 = HC * 4 + 16, NT = 64 * NTOT;
         static_assert(!SPLIT || HC % 16 == 0, "a 16-channel sub-tile belongs to one half");
+        static_assert(!SPLIT || BC % 32 == 0, "a channel tile is whole 32-channel groups");
         constexpr int CPRH = HC / 8, NITH = (BP * CPRH + NT - 1) / NT;       // 8-channel pieces per row of a half / per thread
         const char *__restrict__ res = (const char *)a.res;
-        const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc((char *)a.out + (m0 * a.out_stride + (size_t)ct * BC) * 2);
-        const __amdgpu_buffer_rsrc_t rs_res = tile_rsrc(res ? res + (m0 * a.res_stride + (size_t)ct * BC) * 2 : nullptr);
-        const unsigned out_sb = a.out_stride * 2u, res_sb = a.res_stride * 2u, oblk = (unsigned)a.out_blk * 2u, rblk = (unsigned)a.res_blk * 2u;
+        const __amdgpu_buffer_rsrc_t rs_out = tile_rsrc((char *)a.out + (m0 * a.out_stride + (size_t)ct * BC * 2) * 2);
+        const __amdgpu_buffer_rsrc_t rs_res = tile_rsrc(res ? res + (m0 * a.res_stride + (size_t)ct * BC * 2) * 2 : nullptr);
+        const unsigned out_sb = a.out_stride * 2u, res_sb = a.res_stride * 2u;
+        const int cout32 = (a.Cout + 31) & ~31;
         int prow4[HALO ? TP : 1];
         if constexpr (HALO) {
 #pragma unroll
@@ -753,21 +823,23 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         };
         static_for<2>([&](auto halfc) {
             constexpr int HALF = decltype(halfc)::value;
-            // this thread's shortcut pieces of the half (hi and lo blocks), requested ahead of the barrier and the LDS pass
+            // this thread's shortcut pieces of the half (hi and lo), requested ahead of the barrier and the LDS pass
             u32x4_t rh[NITH], rl[NITH];
             unsigned offs[NITH];
 #pragma unroll
             for (int it = 0; it < NITH; ++it) {
                 int row, cc;
-                unsigned off = piece_off(tid + it * NT, CPRH, 8, out_sb, row, cc);
-                if (ct * BC + HALF * HC + cc * 8 >= a.Cout || ((BP * CPRH) % NT != 0 && tid + it * NT >= BP * CPRH)) off = OOB_OFFSET;
-                offs[it] = off == OOB_OFFSET ? OOB_OFFSET : off + (unsigned)(HALF * HC * 2);
+                unsigned off = piece_off(tid + it * NT, CPRH, 0, out_sb, row, cc);
+                const int cw = HALF * HC + cc * 8;                               // first channel of the piece within the tile
+                const unsigned ilv = ((unsigned)(cw >> 5) << 7) | ((unsigned)(cw & 31) << 1);      // byte offset of its hi piece from the tile's first group
+                if (ct * BC + cw >= cout32 || ((BP * CPRH) % NT != 0 && tid + it * NT >= BP * CPRH)) off = OOB_OFFSET;
+                offs[it] = off == OOB_OFFSET ? OOB_OFFSET : off - (unsigned)cc * 16u + ilv;
                 if (res) {
                     int r2, c2;
-                    unsigned ro = piece_off(tid + it * NT, CPRH, 8, res_sb, r2, c2);
-                    ro = off == OOB_OFFSET ? OOB_OFFSET : ro + (unsigned)(HALF * HC * 2);
+                    unsigned ro = piece_off(tid + it * NT, CPRH, 0, res_sb, r2, c2);
+                    ro = off == OOB_OFFSET || ro == OOB_OFFSET ? OOB_OFFSET : ro - (unsigned)c2 * 16u + ilv;
                     rh[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, RES_LOAD_AUX);
-                    rl[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro == OOB_OFFSET ? OOB_OFFSET : ro + rblk, 0, RES_LOAD_AUX);
+                    rl[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro == OOB_OFFSET ? OOB_OFFSET : ro + 64u, 0, RES_LOAD_AUX);
                 }
             }
             block_barrier();                                  // the stages (half 0) / the previous half's tile (half 1) are no longer read
@@ -805,9 +877,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                     split8(v, H, L);
                 }
                 const unsigned off = offs[it];
-                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off, 0, OUT_STORE_AUX);       // (an unstored piece: OOB_OFFSET + a block offset is still out of range)
-                __builtin_amdgcn_raw_buffer_store_b128(L, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + oblk, 0, OUT_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + 2u * oblk, 0, OUT_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(H, rs_out, off, 0, OUT_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(L, rs_out, off == OOB_OFFSET ? OOB_OFFSET : off + 64u, 0, OUT_STORE_AUX);
             }
         });
         }

@@ -372,10 +372,11 @@ hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, flo
 }
 
 // ---- split fp16 storage (YOLO_FP16X2): a value v is the pair hi = f16(v), lo = f16(v - hi) -- 22 significant bits out of two 11-bit
-//      halves.  A tensor is [pixel][3 * Cp] f16 (Cp = channels rounded up to 8): blocks hi | lo | hi, so that an ordinary fp16 conv over
-//      3 * Cp "channels" with filter rows W_hi | W_hi | W_lo computes W_hi x_hi + W_hi x_lo + W_lo x_hi (what is dropped is W_lo x_lo,
-//      2^-22 of the product): the conv kernels need nothing but a second store pass (conv_igemm_kernel.h, SPLIT).  These are the
-//      memory-bound pieces around them. ----
+//      halves.  A layer output is stored INTERLEAVED (round 6): per 32-channel group 32 hi then 32 lo, [pixel][2 * Cp], Cp = channels rounded
+//      up to 32 -- a 128-byte run of a pixel is one K-step row [hi | lo] of the conv that reads it, which forms W_hi x_hi + W_lo x_hi +
+//      W_hi x_lo from it (conv_igemm_kernel.h, PAIRK; what is dropped is W_lo x_lo, 2^-22 of the product).  The network input keeps rounds
+//      4-5's three blocks hi | lo | hi of its 8 padded channels (PAIR_B3), read by an ordinary fp16 K loop against W_hi | W_hi | W_lo.
+//      These are the memory-bound pieces around the convs. ----
 __device__ __forceinline__ void split8(const float *v, uint4 &H, uint4 &L)
 {
     typedef Elt<f16_t> E;
@@ -386,62 +387,67 @@ __device__ __forceinline__ void split8(const float *v, uint4 &H, uint4 &L)
     for (int i = 0; i < 4; ++i) { const E::h2 h = __builtin_bit_cast(E::h2, w[i]); lo[2 * i] = v[2 * i] - (float)h[0]; lo[2 * i + 1] = v[2 * i + 1] - (float)h[1]; }
     L = uint4{E::pk(lo[0], lo[1]), E::pk(lo[2], lo[3]), E::pk(lo[4], lo[5]), E::pk(lo[6], lo[7])};
 }
-__device__ __forceinline__ void join8(const f16_t *p, int Cp, float *v)
+// element offset of the hi piece of channels [g * 8, g * 8 + 8) inside a pixel, and the distance to its lo piece
+__device__ __forceinline__ int pair_hi_off(int g, int Cp, int layout) { const int c = g * 8; return layout == PAIR_B3 ? c : (c >> 5) * 64 + (c & 31); }
+__device__ __forceinline__ int pair_lo_dist(int Cp, int layout) { return layout == PAIR_B3 ? Cp : 32; }
+__device__ __forceinline__ void join8(const f16_t *p, int lo_dist, float *v)
 {
     float h[8], l[8];
-    Elt<f16_t>::load8(p, h); Elt<f16_t>::load8(p + Cp, l);
+    Elt<f16_t>::load8(p, h); Elt<f16_t>::load8(p + lo_dist, l);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = h[i] + l[i];
 }
-__device__ __forceinline__ void put_split8(f16_t *p, int Cp, const float *v)
+__device__ __forceinline__ void put_split8(f16_t *p, int Cp, int layout, const float *v)
 {
     uint4 H, L; split8(v, H, L);
-    *(uint4 *)p = H; *(uint4 *)(p + Cp) = L; *(uint4 *)(p + 2 * Cp) = H;
+    *(uint4 *)p = H; *(uint4 *)(p + pair_lo_dist(Cp, layout)) = L;
+    if (layout == PAIR_B3) *(uint4 *)(p + 2 * Cp) = H;
 }
-__global__ void k_split_from_f32(const float *in, int is, f16_t *out, int Cp, size_t npix)
+__global__ void k_split_from_f32(const float *in, int is, f16_t *out, int os, int Cp, size_t npix, int layout)
 {
     const int c8 = Cp / 8;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c8) return;
     size_t p = idx / c8; int g = (int)(idx - p * c8);
     float v[8]; Elt<float>::load8(in + p * is + g * 8, v);
-    put_split8(out + p * 3 * Cp + g * 8, Cp, v);
+    put_split8(out + p * os + pair_hi_off(g, Cp, layout), Cp, layout, v);
 }
-__global__ void k_split_to_f32(const f16_t *in, int Cp, float *out, int os, size_t npix)
+__global__ void k_split_to_f32(const f16_t *in, int is, int Cp, float *out, int os, size_t npix, int layout)
 {
     const int c8 = Cp / 8;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c8) return;
     size_t p = idx / c8; int g = (int)(idx - p * c8);
-    float v[8]; join8(in + p * 3 * Cp + g * 8, Cp, v);
+    float v[8]; join8(in + p * is + pair_hi_off(g, Cp, layout), pair_lo_dist(Cp, layout), v);
     Elt<float>::store8(out + p * os + g * 8, v);
 }
 // shortcut on split tensors: (a_hi + a_lo) + (b_hi + b_lo), split again (each parenthesis is exact in fp32 when the pair came from split8)
-__global__ void k_add_split(const f16_t *a, const f16_t *b, f16_t *o, int Cp, size_t npix)
+__global__ void k_add_split(const f16_t *a, int as, const f16_t *b, int bs, f16_t *o, int os, int Cp, size_t npix)
 {
     const int c8 = Cp / 8;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * c8) return;
     size_t p = idx / c8; int g = (int)(idx - p * c8);
+    const int ho = pair_hi_off(g, Cp, PAIR_ILV);
     float x[8], y[8];
-    join8(a + p * 3 * Cp + g * 8, Cp, x); join8(b + p * 3 * Cp + g * 8, Cp, y);
+    join8(a + p * as + ho, 32, x); join8(b + p * bs + ho, 32, y);
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = x[i] + y[i];
-    put_split8(o + p * 3 * Cp + g * 8, Cp, x);
+    put_split8(o + p * os + ho, Cp, PAIR_ILV, x);
 }
-hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int Cp, size_t npix, hipStream_t s)
+hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s, int layout)
 {
-    hipLaunchKernelGGL(k_split_from_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, in, in_stride, (f16_t *)out, Cp, npix);
+    hipLaunchKernelGGL(k_split_from_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, in, in_stride, (f16_t *)out, out_stride, Cp, npix, layout);
     return hipGetLastError();
 }
-hipError_t launch_split_to_f32(const void *in, int Cp, float *out, int out_stride, size_t npix, hipStream_t s)
+hipError_t launch_split_to_f32(const void *in, int in_stride, int Cp, float *out, int out_stride, size_t npix, hipStream_t s, int layout)
 {
-    hipLaunchKernelGGL(k_split_to_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)in, Cp, out, out_stride, npix);
+    hipLaunchKernelGGL(k_split_to_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)in, in_stride, Cp, out, out_stride, npix, layout);
     return hipGetLastError();
 }
-hipError_t launch_add_split(const void *a, const void *b, void *out, int Cp, size_t npix, hipStream_t s)
+hipError_t launch_add_split(const void *a, int a_stride, const void *b, int b_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_add_split, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)a, (const f16_t *)b, (f16_t *)out, Cp, npix);
+    hipLaunchKernelGGL(k_add_split, grid_for(npix * (Cp / 8)), dim3(256), 0, s, (const f16_t *)a, a_stride, (const f16_t *)b, b_stride, (f16_t *)out, out_stride, Cp, npix);
     return hipGetLastError();
 }
 

@@ -60,8 +60,10 @@ struct ConvArgs {
     // per-output-channel dequantisation factor of the accumulator (filter scale; input scales are folded into the
     // filters), `out_inv_scale` = 1 / scale of the output tensor, `res_scale` = scale of the residual tensor.
     int in_dt;
-    int split;                           // 1: split fp16 output (YOLO_FP16X2): every 16-bit output value is stored as hi | lo | hi in three blocks `out_blk` elements apart
-    int out_blk, res_blk;                // (res_blk: the same for the shortcut source)
+    int split;                           // 1: split fp16 OUTPUT (YOLO_FP16X2): every 16-bit output value is stored as the pair hi | lo, interleaved per 32-channel group
+                                         //    (64 bytes of hi, then 64 bytes of lo); out_stride >= 2 * roundup(Cout, 32) elements; the shortcut source (res) has the same form
+    int pairk;                           // 1: the INPUT is such an interleaved pair tensor (Cin_pad = 2 * roundup(Cin, 32) elements per tap) and the filters are packed
+                                         //    W_hi 32 | W_lo 32 per group: the conv runs the pair K loop (three MFMA products per K-step row pair, conv_igemm_kernel.h PAIRK)
     const float *oscale;                 // [Cout_pad] or nullptr (== 1)
     float out_inv_scale, res_scale;
     float mid_scale, mid_inv_scale;      // fused shortcut: this conv's own output scale (quantised before the add)
@@ -138,6 +140,8 @@ bool conv_cfg_tail_ok(int cfg, int cout, bool fp8, bool head = false);      // c
 // fp8 (e4m3 x e4m3 -> fp32, v_mfma_f32_16x16x128_f8f6f4) variant of the same kernel; only the 128-B-row tile configs
 bool conv_cfg_fp8_ok(int cfg);
 bool conv_cfg_split_ok(int cfg);      // tile configurations instantiated for split fp16 storage (YOLO_FP16X2)
+bool conv_cfg_pairk_ok(int cfg, bool split_out);      // ... and for a conv that READS interleaved pairs (pair K loop), writing pairs / plain fp16 or an fp32 head
+hipError_t launch_conv_pair(const ConvArgs &a, int cfg, hipStream_t s);      // the tiled pair-K-loop instantiations (conv_pair.hip); the halo ones: launch_conv_halo13
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
 // fused stem: conv 3x3/s1 (3 -> 32) + conv 3x3/s2 (32 -> 64), bf16 (conv_stem.hip)
@@ -203,10 +207,13 @@ hipError_t launch_copy(const TView &in, const TView &out, hipStream_t s);
 hipError_t launch_local(const TView &in, const TView &out, const void *w, const float *bias, int k, int stride, int pad, int act, hipStream_t s);
 hipError_t launch_to_f32(const TView &in, float *out, hipStream_t s, float scale = 1.f);   // dense NHWC fp32 copy (* scale)
 hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, float scale = 1.f);   // (in * scale) -> view
-// split fp16 storage (YOLO_FP16X2; ew_ops.hip): tensors [pixel][3 * Cp] f16 = hi | lo | hi blocks of Cp = roundup(C, 8) channels
-hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int Cp, size_t npix, hipStream_t s);   // dense-ish fp32 [pixel][in_stride >= Cp] -> split
-hipError_t launch_split_to_f32(const void *in, int Cp, float *out, int out_stride, size_t npix, hipStream_t s);      // split -> fp32 (hi + lo)
-hipError_t launch_add_split(const void *a, const void *b, void *out, int Cp, size_t npix, hipStream_t s);            // shortcut on split tensors
+// split fp16 storage (YOLO_FP16X2; ew_ops.hip).  Two layouts of a pair tensor of Cp padded channels:
+//   PAIR_ILV  [pixel][stride >= 2 * Cp], Cp a multiple of 32: per 32-channel group 32 hi then 32 lo (every layer output; round 6)
+//   PAIR_B3   [pixel][3 * Cp], Cp a multiple of 8: blocks hi | lo | hi (the network INPUT only: 8 padded channels, rounds 4-5's form)
+enum { PAIR_ILV = 0, PAIR_B3 = 1 };
+hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s, int layout = PAIR_ILV);   // fp32 [pixel][in_stride >= Cp] -> pairs
+hipError_t launch_split_to_f32(const void *in, int in_stride, int Cp, float *out, int out_stride, size_t npix, hipStream_t s, int layout = PAIR_ILV);      // pairs -> fp32 (hi + lo)
+hipError_t launch_add_split(const void *a, int a_stride, const void *b, int b_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s);      // shortcut on interleaved pair tensors
 
 // ---- head decode + postprocess (post_ops.hip) ---------------------------------------------------
 struct DecodeArgs {

@@ -206,9 +206,9 @@ int yolo_layer_output(yolo_ctx *c, int index, int n, float *out, size_t out_floa
     hipError_t e = hipSuccess;
     float *wide = nullptr;
     if (L.pair && v.dt == DT_F16) {        // split pairs: join into a Cp-strided fp32 image first, then gather the C logical channels
-        const int cp = v.stride / 3;
+        const int cp = roundup(L.C, 32);
         e = hipMalloc((void **)&wide, (size_t)n * L.H * L.W * cp * 4);
-        if (e == hipSuccess) e = launch_split_to_f32(v.ptr, cp, wide, cp, (size_t)n * L.H * L.W, c->stream);
+        if (e == hipSuccess) e = launch_split_to_f32(v.ptr, v.stride, cp, wide, cp, (size_t)n * L.H * L.W, c->stream);
         v.ptr = wide; v.stride = cp; v.dt = DT_F32;
     }
     if (e == hipSuccess) e = launch_to_f32(v, tmp, c->stream, vs);

@@ -33,7 +33,7 @@ struct Layer {
     void *d_wf = nullptr;                   // bf16 1x1 conv that can ride in its producer's epilogue: its filters in MFMA-fragment order (tail_fragments)
     int in_dt = DT_BF16;                 // operand type of this conv's MFMA (filters are stored in it)
     int store_dt = DT_BF16;              // element type of this layer's output tensor (mixed plans: an fp8 network with bf16 islands, cfg key yolo_store)
-    bool pair = false;                   // YOLO_FP16X2 networks: this layer's output tensor is split-fp16 PAIRS ([pixel][hi | lo | hi], 3 x the channels); false there:
+    bool pair = false;                   // YOLO_FP16X2 networks: this layer's output tensor is split-fp16 PAIRS (interleaved per 32-channel group, 2 x the channels); false there:
                                          // plain fp16 (mixed plans, cfg key yolo_pair=0 on a [convolutional] section; layers that move data inherit their operands' form)
     int tile_cfg = -1;
     int residual_from = -2;              // >= -1: fused shortcut source
@@ -112,7 +112,8 @@ struct yolo_ctx {
     // layer i (1 by default); eff_scale[i] is the scale of the tensor layer i's view holds (inherited through
     // upsample / maxpool / reorg / single-input route; NaN for multi-input routes, which are per channel).
     std::vector<float> user_scale, eff_scale;
-    // split fp16 storage (YOLO_FP16X2): a logical tensor of C channels is [pixel][3 * Cp] f16, Cp = roundup(C, 8): hi | lo | hi blocks
+    // split fp16 storage (YOLO_FP16X2): a layer output of C channels is [pixel][2 * Cp] f16, Cp = roundup(C, 32), interleaved per 32-channel group (32 hi | 32 lo);
+    // the network input [pixel][3 * 8]: hi | lo | hi blocks of its 8 padded channels
     bool split() const { return dtype == YOLO_FP16X2; }
     bool in_pair = false;                 // ... the network input is stored as pairs ([net] yolo_pair_input, default 1 in a YOLO_FP16X2 network)
     bool pair_of(int idx) const { return idx < 0 ? in_pair : layers[idx].pair; }      // is tensor `idx` (-1: the input) stored as pairs?
@@ -131,6 +132,7 @@ int fail(yolo_ctx *c, int code, const char *fmt, ...);
         if (e_ != hipSuccess) return fail(c, YOLO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+inline int pair_width(int C) { return 2 * roundup(C, 32); }      // elements per pixel of an interleaved split-fp16 pair tensor of C channels (32 hi | 32 lo per group)
 inline int gran_of(int dt) { return dt == DT_FP8 ? 16 : 8; }      // channels per 16-byte piece (8 for fp32 tensors too)
 inline void drop_graph(yolo_ctx *c) { if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } if (c->gstate > 0) c->gstate = 0; }      // a plan / parameter change: the captured detect step must not be replayed
 
@@ -139,7 +141,7 @@ uint16_t f2bf(float f);
 uint16_t f2h(float f);
 uint8_t f2e4m3(float f);
 void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
-               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics = YOLO_SEM_TF, bool split = false);
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics = YOLO_SEM_TF, int split = 0);      // split: 0 plain, 1 pair input in three blocks (the image), 2 interleaved pair input
 float h2f(uint16_t h);
 void resolve_scales(yolo_ctx *c);
 void channel_scales(const yolo_ctx *c, int idx, std::vector<float> &out);

@@ -23,48 +23,56 @@ TView make_view(void *p, int n, int h, int w, int c, int stride, int dt) { TView
 extern "C" {
 
 // ---- single operators -----------------------------------------------------------------------
-// yolo_op_conv2d for dtype YOLO_FP16X2: x (and the residual) enter as split fp16 pairs, the filters as W_hi | W_hi | W_lo rows, the conv runs
-// on the SPLIT instantiation, the shortcut (if any) as the separate k_add_split launch of that configuration, the result is joined to fp32
+// yolo_op_conv2d for dtype YOLO_FP16X2: x (and the residual) enter as interleaved split-fp16 pairs (32 hi | 32 lo per 32-channel group), the
+// filters as W_hi 32 | W_lo 32 rows, the conv runs the pair K loop with the SPLIT epilogue, the shortcut (if any) folded into it or
+// (YOLO_SPLIT_UNFUSED) as the separate k_add_split launch of that configuration; the result is joined to fp32
 static int op_conv2d_split(const float *x, int n, int h, int w, int cin, const float *w_hwio, const float *bias, int k, int stride,
                            int cout, int act, const float *residual, float *out, int tile_cfg, int device)
 {
     if (cin % 8 || cout % 8) { g_op_err = "conv2d (fp16x2): channel counts must be multiples of 8"; return YOLO_ERR_INVALID; }
     OpScope S(device); if (S.rc) { g_op_err = "conv2d: no HIP device"; return S.rc; }
+    const int cpi = roundup(cin, 32), cpo = roundup(cout, 32);
     Layer L; L.type = L_CONV; L.filters = cout; L.size = k; L.stride = stride; L.pad = k / 2; L.bn = 0; L.act = act; L.in_dt = DT_F16;
-    L.cin = cin; L.cin_pad = 3 * cin; L.kpad = roundup(k * k * L.cin_pad, 64); L.cout_pad = roundup(cout, 256);
+    L.cin = cin; L.cin_pad = 2 * cpi; L.kpad = k * k * L.cin_pad; L.cout_pad = roundup(cout, 256);
     const int ho = (h + 2 * L.pad - k) / stride + 1, wo = (w + 2 * L.pad - k) / stride + 1;
     std::vector<float> oihw((size_t)cout * cin * k * k), b0(cout, 0.f);
     for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) for (int ci = 0; ci < cin; ++ci) for (int o = 0; o < cout; ++o)
         oihw[(((size_t)o * cin + ci) * k + kh) * k + kw] = w_hwio[(((size_t)kh * k + kw) * cin + ci) * cout + o];
     if (bias) memcpy(b0.data(), bias, (size_t)cout * 4);
-    std::vector<uint8_t> wbuf; std::vector<float> bv, osc; pack_conv(L, b0.data(), oihw.data(), DT_F16, nullptr, wbuf, bv, osc, YOLO_SEM_TF, true);
+    std::vector<uint8_t> wbuf; std::vector<float> bv, osc; pack_conv(L, b0.data(), oihw.data(), DT_F16, nullptr, wbuf, bv, osc, YOLO_SEM_TF, 2);
     void *d_w = S.upload(wbuf.data(), wbuf.size()); float *d_b = (float *)S.upload(bv.data(), bv.size() * 4);
     const size_t pin = (size_t)n * h * w, pout = (size_t)n * ho * wo;
-    float *d_x32 = (float *)S.upload(x, pin * cin * 4);
-    void *d_x = S.alloc(pin * 3 * cin * 2), *d_o = S.alloc(pout * 3 * cout * 2), *d_z = S.alloc(4096);
-    float *d_o32 = (float *)S.alloc(pout * cout * 4);
+    // fp32 images padded to whole 32-channel groups (zeros): the split kernels read whole groups
+    auto upload_padded = [&](const float *src, size_t npix, int c, int cp) -> float * {
+        float *d = (float *)S.alloc(npix * cp * 4);
+        if (d && hipMemcpy2DAsync(d, (size_t)cp * 4, src, (size_t)c * 4, (size_t)c * 4, npix, hipMemcpyHostToDevice, S.s) != hipSuccess) S.rc = YOLO_ERR_HIP;
+        return d;
+    };
+    float *d_x32 = upload_padded(x, pin, cin, cpi);
+    void *d_x = S.alloc(pin * 2 * cpi * 2), *d_o = S.alloc(pout * 2 * cpo * 2), *d_z = S.alloc(4096);
+    float *d_o32 = (float *)S.alloc(pout * cpo * 4);
     if (S.rc) { g_op_err = "conv2d: allocation failed"; return S.rc; }
-    if (!S.ok(launch_split_from_f32(d_x32, cin, d_x, cin, pin, S.s))) { g_op_err = S.err; return S.rc; }
+    if (!S.ok(launch_split_from_f32(d_x32, cpi, d_x, 2 * cpi, cpi, pin, S.s))) { g_op_err = S.err; return S.rc; }
     ConvArgs a; memset(&a, 0, sizeof a);
-    a.in = d_x; a.in_stride = 3 * cin; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = 3 * cout; a.out_dt = DT_F16; a.in_dt = DT_F16;
-    a.split = 1; a.out_blk = cout; a.out_inv_scale = a.res_scale = a.mid_scale = a.mid_inv_scale = 1.f;
+    a.in = d_x; a.in_stride = 2 * cpi; a.wt = d_w; a.bias = d_b; a.out = d_o; a.out_stride = 2 * cpo; a.out_dt = DT_F16; a.in_dt = DT_F16;
+    a.split = 1; a.pairk = 1; a.out_inv_scale = a.res_scale = a.mid_scale = a.mid_inv_scale = 1.f;
     a.N = n; a.H = h; a.W = w; a.Cin_pad = L.cin_pad; a.Ho = ho; a.Wo = wo; a.Cout = cout;
     a.ksize = k; a.stride = stride; a.pad = L.pad; a.Kpad = L.kpad; a.kchunk = conv_kchunk(L.cin_pad, DT_F16); a.act = act; a.zeros = d_z;
     conv_finalize(a);
     int cfg = tile_cfg >= 0 ? tile_cfg : 6;
-    if (!conv_cfg_split_ok(cfg) || (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
+    if (!conv_cfg_pairk_ok(cfg, true) || (conv_cfg_is_halo(cfg) && !conv_halo_cfg_ok(a, cfg))) { g_op_err = "conv2d (fp16x2): tile config not instantiated for split storage / not applicable to this shape"; return YOLO_ERR_UNSUPPORTED; }
     // the shortcut: fused into the conv's epilogue, or (YOLO_SPLIT_UNFUSED, the parity tests' A/B) as the separate launch a keep_layers plan makes
     void *d_r = nullptr;
     if (residual) {
-        float *d_r32 = (float *)S.upload(residual, pout * cout * 4); d_r = S.alloc(pout * 3 * cout * 2);
+        float *d_r32 = upload_padded(residual, pout, cout, cpo); d_r = S.alloc(pout * 2 * cpo * 2);
         if (S.rc) return S.rc;
-        if (!S.ok(launch_split_from_f32(d_r32, cout, d_r, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
-        if (!getenv("YOLO_SPLIT_UNFUSED")) { a.res = d_r; a.res_stride = 3 * cout; a.res_blk = cout; }
+        if (!S.ok(launch_split_from_f32(d_r32, cpo, d_r, 2 * cpo, cpo, pout, S.s))) { g_op_err = S.err; return S.rc; }
+        if (!getenv("YOLO_SPLIT_UNFUSED")) { a.res = d_r; a.res_stride = 2 * cpo; }
     }
     if (!S.ok(launch_conv_bf16(a, cfg, S.s))) { g_op_err = "conv2d launch: " + S.err; return S.rc; }
-    if (residual && !a.res && !S.ok(launch_add_split(d_o, d_r, d_o, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
-    if (!S.ok(launch_split_to_f32(d_o, cout, d_o32, cout, pout, S.s))) { g_op_err = S.err; return S.rc; }
-    S.download(out, d_o32, pout * cout * 4);
+    if (residual && !a.res && !S.ok(launch_add_split(d_o, 2 * cpo, d_r, 2 * cpo, d_o, 2 * cpo, cpo, pout, S.s))) { g_op_err = S.err; return S.rc; }
+    if (!S.ok(launch_split_to_f32(d_o, 2 * cpo, cpo, d_o32, cpo, pout, S.s))) { g_op_err = S.err; return S.rc; }
+    if (hipMemcpy2DAsync(out, (size_t)cout * 4, d_o32, (size_t)cpo * 4, (size_t)cout * 4, pout, hipMemcpyDeviceToHost, S.s) != hipSuccess || hipStreamSynchronize(S.s) != hipSuccess) S.rc = YOLO_ERR_HIP;
     if (S.rc) g_op_err = "conv2d: " + std::string(hipGetErrorString(hipGetLastError()));
     return S.rc;
 }

@@ -63,7 +63,7 @@ float h2f(uint16_t h)
 }
 
 void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int wdt, const float *in_scale,
-               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics, bool split)
+               std::vector<uint8_t> &wbuf, std::vector<float> &bias, std::vector<float> &osc, int semantics, int split)
 {
     const int n = L.filters, k = L.size, cin = L.cin;
     bias.assign(L.cout_pad, 0.f); osc.assign(L.cout_pad, 1.f);
@@ -95,8 +95,17 @@ void pack_conv(const Layer &L, const float *bn_or_bias, const float *w_oihw, int
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < k * k; ++t) {
                 const float v = row[(size_t)ci * k * k + t];
+                if (split == 2) {
+                    // split fp16 (YOLO_FP16X2), the input is an interleaved pair tensor (pair K loop): per 32-channel group and tap one 64-element
+                    // K-step row W_hi 32 | W_lo 32 -- k = ((ci / 32) * k * k + t) * 64 + ci % 32 (+ 32 for the low half)
+                    const uint16_t h = f2h(v); const uint16_t l = f2h(v - h2f(h));
+                    const size_t idx = (size_t)o * L.kpad + ((size_t)(ci / 32) * k * k + t) * 64 + ci % 32;
+                    memcpy(&wbuf[idx * 2], &h, 2); memcpy(&wbuf[(idx + 32) * 2], &l, 2);
+                    continue;
+                }
                 if (split) {
-                    // split fp16 (YOLO_FP16X2): the kernel walks 3 * Cp input 'channels' hi | lo | hi; the filter row holds W_hi | W_hi | W_lo
+                    // ... the input is the network image, three blocks hi | lo | hi of its 8 padded channels (plain K loop over 3 * Cp 'channels'):
+                    // the filter row holds W_hi | W_hi | W_lo
                     const int Cp = L.cin_pad / 3;
                     const uint16_t h = f2h(v); const uint16_t l = f2h(v - h2f(h));
                     for (int blk = 0; blk < 3; ++blk) {
@@ -253,7 +262,7 @@ int yolo_set_weights(yolo_ctx *c, const float *flat, size_t n)
                             wperm[(((size_t)o * 32 + (dy * 2 + dx) * 8 + ch) * 4 + a4) * 4 + b4] = w[(((size_t)o * 3 + ch) * 7 + kh) * 7 + kw]; } }
             w = wperm.data();
         }
-        pack_conv(*PL, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics, c->pair_of(L.in[0]));      // (filter rows W_hi | W_hi | W_lo against a tensor stored as pairs)
+        pack_conv(*PL, params, w, L.in_dt, in_sc.empty() ? nullptr : in_sc.data(), wbuf, bias, osc, c->semantics, !c->pair_of(L.in[0]) ? 0 : L.in[0] < 0 ? 1 : 2);      // (filter rows against a tensor stored as pairs: W_hi | W_hi | W_lo for the image's three blocks, W_hi 32 | W_lo 32 per group for an interleaved layer output)
         HIPCK(c, hipMemcpy(L.d_w, wbuf.data(), wbuf.size(), hipMemcpyHostToDevice));
         HIPCK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
         if (L.d_sc) HIPCK(c, hipMemcpy(L.d_sc, osc.data(), osc.size() * 4, hipMemcpyHostToDevice));
@@ -288,7 +297,7 @@ int yolo_load_darknet_weights(yolo_ctx *c, const char *path, int header_ints)
 namespace {
 struct ArtHeader { char magic[8]; uint32_t version, dtype, semantics, decode, n_layers, num_cfgs, cfg_len, reserved; };
 const char kArtMagic[8] = {'Y', 'O', 'L', 'O', 'H', 'I', 'P', '1'};
-const uint32_t kArtVersion = 2;          // 2: filters packed chunk-major (conv_kchunk); a version-1 file holds tap-major filters
+const uint32_t kArtVersion = 3;          // 3: split-fp16 filters packed for the interleaved pair layout (round 6); 2: filters packed chunk-major (conv_kchunk); 1: tap-major
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
 struct ArtWriter {
     FILE *f; uint64_t h = 1469598103934665603ull; bool ok = true;

@@ -90,7 +90,9 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
                 }
             }
             L.cin = C; L.cin_pad = roundup(C, L.in_dt == DT_FP8 ? 16 : 8);
-            if (c->pair_of(i - 1)) L.cin_pad *= 3;              // the conv kernel's view of a split tensor: 3 * Cp channels (hi | lo | hi)
+            // the conv kernel's view of a pair tensor: a layer output is interleaved per 32-channel group, 2 * roundup(C, 32) elements per
+            // pixel and tap (pair K loop); the network input keeps the three blocks hi | lo | hi of its 8 padded channels (plain K loop)
+            if (c->pair_of(i - 1)) L.cin_pad = i - 1 < 0 ? 3 * roundup(C, 8) : pair_width(C);
             L.pair = c->split() && opt_i(s, "yolo_pair", 1) != 0;
             L.kpad = roundup(L.size * L.size * L.cin_pad, L.in_dt == DT_FP8 ? 128 : 64); L.cout_pad = roundup(L.filters, 256);
             if (L.s2d7) { L.cin_pad = 32; L.kpad = 16 * 32; }          // 4x4 taps x (2x2 positions x 8 padded channels)
@@ -297,11 +299,14 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         int off = 0;
         for (int j : L.in) {
             int cj = j < 0 ? c->in_c : c->layers[j].C;
-            bool ok = !L.pair && j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&      // (split fp16: a concatenation is copied, block by block)
-                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % gran_of(L.store_dt) == 0) && (off % gran_of(L.store_dt) == 0);
+            // (pair tensors, round 6: interleaved per 32-channel group, so a source of whole groups at a whole-group offset is a window of the
+            //  concatenation like any other tensor; element offset 2 x the channel offset)
+            const int gran = L.pair ? 32 : gran_of(L.store_dt);
+            bool ok = j >= 0 && place_route[j] < 0 && c->layers[j].type != L_ROUTE && !c->layers[j].head &&
+                      c->layers[j].type != L_YOLO && c->layers[j].type != L_REGION && c->layers[j].type != L_DETECT && (cj % gran == 0) && (off % gran == 0);
             // a fused-away conv's real producer is the conv; the shortcut layer itself is what gets placed
             if (ok && c->layers[j].type == L_CONV && j + 1 < NL && c->layers[j + 1].noop && c->layers[j + 1].type == L_SHORTCUT) ok = false;
-            if (ok) { place_route[j] = i; place_off[j] = off; }
+            if (ok) { place_route[j] = i; place_off[j] = L.pair ? 2 * off : off; }
             else { L.copy_inputs.push_back(j); L.copy_offsets.push_back(off); }
             off += cj;
         }
@@ -314,7 +319,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
     for (int i = 0; i < NL; ++i) {
         Layer &L = c->layers[i];
         if (L.type == L_ROUTE && L.in.size() >= 2) {
-            L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (L.pair ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
+            L.storage = new_storage(L.pair ? pair_width(L.C) : roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers); L.ch_off = 0;
         }
     }
     for (int i = 0; i < NL; ++i) {
@@ -325,7 +330,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
-        else L.storage = new_storage(roundup(L.C, gran_of(L.store_dt)) * (L.pair ? 3 : 1), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
+        else L.storage = new_storage(L.pair ? pair_width(L.C) : roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
     }
     // a conv whose shortcut was fused writes the shortcut layer's tensor
     for (int i = 0; i + 1 < NL; ++i) {
@@ -393,8 +398,8 @@ int allocate(yolo_ctx *c)
         size_t cap = (size_t)c->max_batch * c->in_h * c->in_w * 8;
         for (auto &L : c->layers) if (L.type == L_UPSAMPLE || L.type == L_MAXPOOL || L.type == L_REORG) {
             const TView in = view_of(c, L.in[0]);
-            cap = std::max(cap, (size_t)c->max_batch * in.h * in.w * roundup(in.c, 8));
-            cap = std::max(cap, (size_t)c->max_batch * L.H * L.W * roundup(L.C, 8));
+            cap = std::max(cap, (size_t)c->max_batch * in.h * in.w * roundup(in.c, 32));
+            cap = std::max(cap, (size_t)c->max_batch * L.H * L.W * roundup(L.C, 32));
         }
         c->f32_cap = cap;
         HIPCK(c, hipMalloc((void **)&c->d_f32a, cap * 4)); HIPCK(c, hipMalloc((void **)&c->d_f32b, cap * 4));
@@ -453,7 +458,7 @@ int allocate(yolo_ctx *c)
     HIPCK(c, hipStreamSynchronize(c->stream));
     // The 16-bit / e4m3 conv kernels address their input with 32-bit buffer offsets: the whole-batch activation window of every conv must
     // stay under 2 GiB (launch_conv_bf16's own check).  Refuse a max_batch that cannot run HERE, with the number that can, instead of a bare
-    // 'invalid value' from the first forward (a split-fp16 tensor is 3 x as wide, so 416 x 416 stops above batch 64).
+    // 'invalid value' from the first forward (a split-fp16 tensor is 2 x as wide, so 416 x 416 stops above batch 96).
     if (c->dtype != YOLO_FP32)
         for (size_t i = 0; i < c->layers.size(); ++i) {
             const Layer &L = c->layers[i];
@@ -462,7 +467,7 @@ int allocate(yolo_ctx *c)
             const double per_image = (double)in.h * in.w * in.stride * dt_size(L.in_dt), slack = 2.0 * (in.w + 1) * in.stride * dt_size(L.in_dt);
             if (per_image * c->max_batch + slack >= 2147483648.0)
                 return fail(c, YOLO_ERR_UNSUPPORTED, "max_batch %d: layer %zu reads %.0f bytes per image%s, and a conv's whole-batch input must stay below 2 GiB (32-bit buffer offsets): at most %d images per context",
-                            c->max_batch, i, per_image, c->split() ? " (split fp16 pairs: 3 x the channels)" : "", (int)((2147483648.0 - slack - 1) / per_image));
+                            c->max_batch, i, per_image, c->split() ? " (split fp16 pairs: 2 x the channels)" : "", (int)((2147483648.0 - slack - 1) / per_image));
         }
     return YOLO_OK;
 }

@@ -18,13 +18,13 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
     TView in = view_of(c, L.in[0]);
     a.in = in.ptr; a.in_stride = in.stride; a.wt = L.d_w; a.bias = L.d_b;
     a.out = L.out.ptr; a.out_stride = L.out.stride; a.out_dt = L.out.dt; a.in_dt = L.in_dt; a.oscale = L.d_sc;
-    // split fp16: a conv that writes PAIRS leaves through the SPLIT epilogue (hi | lo | hi blocks); the fp32 heads of such a network keep
-    // running on the split instantiations too (their tile table); a conv that writes plain fp16 (mixed plans) is the ordinary fp16 kernel,
-    // whatever its input's form -- the K loop only sees 3 x the channels
-    if (L.pair || (c->split() && L.out.dt == DT_F32)) { a.split = 1; a.out_blk = L.out.dt == DT_F32 ? 0 : L.out.stride / 3; }
+    // split fp16: a conv that writes PAIRS leaves through the SPLIT epilogue (interleaved hi | lo groups); the fp32 heads of such a network keep
+    // running on the split instantiations too (their tile table); a conv that writes plain fp16 (mixed plans) has the ordinary fp16 epilogue
+    if (L.pair || (c->split() && L.out.dt == DT_F32)) a.split = 1;
+    a.pairk = L.in[0] >= 0 && c->pair_of(L.in[0]) ? 1 : 0;          // the input is an interleaved pair tensor: the pair K loop (the network input's three blocks: the plain one)
     a.out_inv_scale = 1.f; a.res_scale = 1.f; a.mid_scale = 1.f; a.mid_inv_scale = 1.f;
     const int li = (int)(&L - c->layers.data());
-    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; a.res_blk = c->pair_of(L.residual_from) ? r.stride / 3 : 0; }
+    if (L.residual_from >= -1) { TView r = view_of(c, L.residual_from); a.res = r.ptr; a.res_stride = r.stride; }
     // the tail runs on the producer's operand type: bf16 needs the fragment-order copy of the 1x1 filters (tail_fragments), e4m3 an
     // e4m3-packed 1x1 conv; anything else leaves w2 null and run_layer refuses the plan instead of launching with a null w2f
     if (L.tail_on && L.tail_layer >= 0 && c->layers[L.tail_layer].in_dt == L.in_dt && (L.in_dt == DT_FP8 || c->layers[L.tail_layer].d_wf)) {
@@ -67,16 +67,20 @@ static int via_f32(yolo_ctx *c, const Layer &L, int n, int kind)
 {
     hipStream_t s = c->stream;
     const TView in = view_of(c, L.in[0]);
-    const int cpi = in.stride / 3, cpo = L.out.stride / 3;
+    const int cpi = roundup(in.c, 32), cpo = roundup(L.C, 32);
     const size_t pin = (size_t)n * in.h * in.w, pout = (size_t)n * L.H * L.W;
     if (pin * cpi > c->f32_cap || pout * cpo > c->f32_cap) return fail(c, YOLO_ERR_STATE, "internal: fp32 staging too small");
-    HIPCK(c, launch_split_to_f32(in.ptr, cpi, c->d_f32a, cpi, pin, s));
+    HIPCK(c, launch_split_to_f32(in.ptr, in.stride, cpi, c->d_f32a, cpi, pin, s));
     TView a; a.ptr = c->d_f32a; a.n = n; a.h = in.h; a.w = in.w; a.c = cpi; a.stride = cpi; a.dt = DT_F32;
     TView b; b.ptr = c->d_f32b; b.n = n; b.h = L.H; b.w = L.W; b.c = cpo; b.stride = cpo; b.dt = DT_F32;
     if (kind == 0) HIPCK(c, launch_upsample2x(a, b, c->semantics == YOLO_SEM_TF, s));
     else if (kind == 1) HIPCK(c, launch_maxpool(a, b, L.psize, L.pstride, L.ppad, s));
-    else HIPCK(c, launch_reorg(a, b, L.pstride, c->semantics == YOLO_SEM_DARKNET, s));
-    HIPCK(c, launch_split_from_f32(c->d_f32b, cpo, L.out.ptr, cpo, pout, s));
+    else {          // reorg scrambles channels: it runs on the LOGICAL channel counts (the padding of a pair tensor is not part of it)
+        a.c = in.c; b.c = L.C;
+        if (in.c % 32 || L.C % 32) return fail(c, YOLO_ERR_UNSUPPORTED, "reorg of a pair tensor of %d channels (whole 32-channel groups only)", in.c);
+        HIPCK(c, launch_reorg(a, b, L.pstride, c->semantics == YOLO_SEM_DARKNET, s));
+    }
+    HIPCK(c, launch_split_from_f32(c->d_f32b, cpo, L.out.ptr, L.out.stride, cpo, pout, s));
     return YOLO_OK;
 }
 
@@ -135,8 +139,9 @@ int run_layer(yolo_ctx *c, int i, int n)
             h.res = a.res; h.out = a.out; h.out_stride = a.out_stride; h.N = n; h.H = in.h; h.W = in.w; h.dt = L.in_dt;
             if (conv_s2_ok(h)) { HIPCK(c, launch_conv_s2(h, s)); break; }
         }
-        if (a.split) {
-            int cfg = L.tile_cfg >= 0 && conv_cfg_split_ok(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
+        if (a.split || a.pairk) {
+            auto inst = [&](int cfg) { return a.pairk ? conv_cfg_pairk_ok(cfg, a.split != 0) : conv_cfg_split_ok(cfg); };
+            int cfg = L.tile_cfg >= 0 && inst(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
             if (conv_cfg_is_halo(cfg) && (!conv_halo_cfg_ok(a, cfg) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
@@ -156,7 +161,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         break; }
     case L_SHORTCUT:
         if (!L.noop && L.pair) {
-            HIPCK(c, launch_add_split(view_of(c, L.in[0]).ptr, view_of(c, L.in[1]).ptr, L.out.ptr, L.out.stride / 3, (size_t)n * L.H * L.W, s));
+            HIPCK(c, launch_add_split(view_of(c, L.in[0]).ptr, view_of(c, L.in[0]).stride, view_of(c, L.in[1]).ptr, view_of(c, L.in[1]).stride, L.out.ptr, L.out.stride, roundup(L.C, 32), (size_t)n * L.H * L.W, s));
         } else if (!L.noop) {
             float sa = 1.f, sb = 1.f, so = 1.f;
             if (c->dtype == YOLO_FP8) { sa = c->eff_scale[L.in[0]]; sb = c->eff_scale[L.in[1]]; so = 1.f / c->eff_scale[i]; }
@@ -168,14 +173,11 @@ int run_layer(yolo_ctx *c, int i, int n)
             TView src = nview(view_of(c, L.copy_inputs[k])); TView dst = nview(L.out);
             dst.ptr = (char *)dst.ptr + (size_t)L.copy_offsets[k] * dt_size(dst.dt); dst.c = src.c;
             if (src.c % 8) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of %d channels", src.c);
-            if (L.pair) {        // three blocks of the source into the three blocks of the concatenation
-                const int cps = src.stride / 3, cpd = L.out.stride / 3;
-                for (int blk = 0; blk < 3; ++blk) {
-                    TView sv = src, dv = nview(L.out);
-                    sv.ptr = (char *)src.ptr + (size_t)blk * cps * 2; sv.c = cps;
-                    dv.ptr = (char *)L.out.ptr + ((size_t)blk * cpd + L.copy_offsets[k]) * 2; dv.c = cps;
-                    HIPCK(c, launch_copy(sv, dv, s));
-                }
+            if (L.pair) {        // interleaved pairs: the source's 2 * Cp elements at twice the channel offset (whole 32-channel groups)
+                if (src.c % 32 || L.copy_offsets[k] % 32) return fail(c, YOLO_ERR_UNSUPPORTED, "route copy of a pair tensor: %d channels at offset %d (whole 32-channel groups only)", src.c, L.copy_offsets[k]);
+                TView dv = nview(L.out);
+                dv.ptr = (char *)L.out.ptr + (size_t)2 * L.copy_offsets[k] * 2; dv.c = 2 * src.c; src.c = 2 * src.c;
+                HIPCK(c, launch_copy(src, dv, s));
                 continue;
             }
             HIPCK(c, launch_copy(src, dst, s));
@@ -250,7 +252,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     }
     if (c->in_pair) {        // the image in fp32 (exact for uint8 pixels x scale up to fp32 rounding), then split pairs
         HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->d_f32a, DT_F32, 8, c->stream, c->in_mul, c->in_add));
-        HIPCK(c, launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, npix, c->stream));
+        HIPCK(c, launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 24, 8, npix, c->stream, PAIR_B3));
         return YOLO_OK;
     }
     HIPCK(c, launch_preprocess(src, fmt, n, c->in_h * c->in_w, scale, c->input.ptr, c->input.dt, 8, c->stream, c->in_mul, c->in_add));
@@ -351,7 +353,7 @@ int yolo_forward_image_u8(yolo_ctx *c, const uint8_t *image, int h, int w, int l
     c->stem_u8 = nullptr;
     hipError_t e = c->in_pair ? launch_resize_u8(src, h, w, c->in_h, c->d_f32a, DT_F32, 8, 8, c->stream, c->in_mul, c->in_add)
                               : launch_resize_u8(src, h, w, c->in_h, c->input.ptr, c->input.dt, 8, 8, c->stream, c->in_mul, c->in_add);
-    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
+    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 24, 8, (size_t)c->in_h * c->in_w, c->stream, PAIR_B3);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "resize: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -372,7 +374,7 @@ int yolo_forward_letterbox_chw(yolo_ctx *c, const float *image_chw, int w, int h
     }
     c->stem_u8 = nullptr;
     hipError_t e = c->in_pair ? launch_letterbox_chw(src, w, h, c->in_h, c->d_f32a, DT_F32, 8, c->stream) : launch_letterbox_chw(src, w, h, c->in_h, c->input.ptr, c->input.dt, 8, c->stream);
-    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 8, (size_t)c->in_h * c->in_w, c->stream);
+    if (e == hipSuccess && c->in_pair) e = launch_split_from_f32(c->d_f32a, 8, c->input.ptr, 24, 8, (size_t)c->in_h * c->in_w, c->stream, PAIR_B3);
     int r = e == hipSuccess ? run_network(c, 1) : fail(c, YOLO_ERR_HIP, "letterbox: %s", hipGetErrorString(e));
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     if (r) return r;
@@ -534,12 +536,13 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     const int NL = (int)c->layers.size();
     auto shape_key = [&](const Layer &L) {
         ConvArgs a = conv_args(c, L, n);
-        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d%d_%d%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.in_dt, a.out_dt, a.res != nullptr, a.split);
+        char key[128]; snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d%d_%d%d%d", a.H, a.W, a.Cin_pad, a.Cout, a.ksize, a.stride, a.in_dt, a.out_dt, a.res != nullptr, a.split, a.pairk);
         return std::string(key);
     };
     auto valid = [&](const Layer &L, int cfg) {
         if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
+        if (a.pairk) return conv_cfg_pairk_ok(cfg, a.split != 0) && (!conv_cfg_is_halo(cfg) || (conv_halo_cfg_ok(a, cfg) && a.out_dt != DT_F32));
         if (a.split) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo_cfg_ok(a, cfg) && a.out_dt != DT_F32));
         if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
@@ -547,7 +550,7 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     };
     for (auto &L : c->layers) L.tail_on = false;
     std::vector<int> fallback(NL, -1);
-    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = a.split ? split_default_cfg(a) : conv_pick_cfg(a); }
+    for (int i = 0; i < NL; ++i) if (c->layers[i].type == L_CONV && !fixed_kernel(c->layers[i])) { ConvArgs a = conv_args(c, c->layers[i], n); fallback[i] = (a.split || a.pairk) ? split_default_cfg(a) : conv_pick_cfg(a); }
     std::map<std::string, std::map<int, double>> score;          // shape -> cfg -> summed ms over the layers of that shape
     std::vector<float> ms(NL);
     for (int ci = 0; ci <= conv_num_cfgs(); ++ci) {
