@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg (`latency_b1_ms`: one image per call, graph replay, synchronised per image; rank 0, N = 1, outside the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--retune", action="store_true", help="ignore the persisted tile plan and autotune")
+    ap.add_argument("--no-tune", action="store_true", help="no committed tile plan for this (size, batch, dtype): run the library's built-in plan instead of autotuning (functional runs)")
     ap.add_argument("--dtype", choices=("bf16", "fp8", "fp32", "fp16", "mixed", "fp16x2", "mixed16"), default="bf16",
                     help="bf16 is BASELINE.json's headline configuration; fp8 is its config 5; fp32 is the exact-fp32 MFMA path, the one "
                          "that meets north_star's IoU >= 0.999; fp16 is the bf16 configuration with IEEE fp16 storage (same kernels, plans and "
@@ -226,9 +227,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"      # exercise the RCCL path at world size 1 (testing only)
+    # BENCH_BACKEND=gloo: a FUNCTIONAL multi-rank run on whatever GPUs there are -- ranks beyond the device count share GPUs (two ranks on the one
+    # GPU of a test box), the box records are exchanged through pinned host buffers by gloo instead of RCCL (dist.HostStagedGather).  It runs
+    # every line of the N > 1 path (shard bounds, per-rank seeds, ragged splits, the pipelined exchange, the MAX-reduce, the rank-0 print) on a
+    # real device; it says nothing about scaling, and the line says so.  (device_count() does not initialise the GPU on this image.)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -284,7 +295,7 @@ def main():
     # rank ends up with the global batch in rank order)
     rec, boxes, counts = ydist.alloc_flat_records(B, max_out, dev)
     # the exchange of step n runs under the compute of step n+1 (dist.PipelinedGather); the last one is waited for inside the timed region
-    gather = ydist.PipelinedGather(rec) if (world > 1 or force_dist) else None
+    gather = (ydist.HostStagedGather(rec) if backend == "gloo" else ydist.PipelinedGather(rec)) if (world > 1 or force_dist) else None
     eng.forward(images, want_detections=False)
     # per-layer tile choices: reuse a persisted plan for this (workload, batch) if one is committed, else autotune
     # (fp16 runs the bf16 configuration's kernels shape for shape: it shares that plan)
@@ -298,7 +309,9 @@ def main():
                 eng.set_tile_configs(plan["cfgs"]); loaded = True
         except Exception:      # noqa: BLE001
             loaded = False
-    if not loaded:
+    if not loaded and args.no_tune:
+        pass                      # the library's built-in plan (functional runs at batch sizes without a committed plan)
+    elif not loaded:
         eng.autotune(B, int(os.environ.get("BENCH_TUNE_ITERS", "5")))
         if rank == 0:
             out_dir = os.path.join(ROOT, "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
@@ -336,10 +349,25 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if G > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
+    exchange_ok = None
+    if gather is not None and backend == "gloo":
+        # functional check of the exchange: one more step, gathered; this rank's slot must hold its own records, and the counts of all ranks
+        # must be those of n_local real images followed by the zero padding of a short rank
+        step(); allrec = gather.result()
+        mine = rec.cpu()
+        ok = bool(torch.equal(allrec[rank], mine))
+        for r in range(G):
+            rlo, rhi = ydist.shard_bounds(GB, G, r)
+            cnt = allrec[r][B * max_out * ydist.RECORD_FLOATS:]
+            ok = ok and bool((cnt[rhi - rlo:] == 0).all()) and bool((cnt[:rhi - rlo] >= 0).all()) and bool((cnt[:rhi - rlo] <= max_out).all())
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if G > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(flag.item())
 
     if rank == 0:
         total_ms, conv_ms = eng.time_forward(n_local, 10, conv=True)
@@ -376,6 +404,10 @@ def main():
                          "kernel": "conv_igemm_f32 (every conv launch of one forward)" if fp32 else "conv_igemm + conv_stem (every conv launch of one forward)", "flops_per_forward": flops,
                          "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4)},
         }
+        if backend == "gloo" and (G > 1 or force_dist):
+            out["backend"] = ("gloo: FUNCTIONAL multi-rank run -- %d ranks on %d GPU(s), box records exchanged through pinned host buffers; exercises the N > 1 "
+                              "code path, not a scaling measurement" % (G, max(1, torch.cuda.device_count())))
+            out["exchange_check"] = exchange_ok
         if hip.LIB_OVERRIDE:
             out["lib_override"] = hip.LIB_OVERRIDE          # measured through YOLO_HIP_LIB (an A/B probe build), not the in-tree library
         if strong:      # a fixed global batch leaves each rank a small share: say which regime that share runs in, so a poor strong curve reads correctly

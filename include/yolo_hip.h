@@ -254,6 +254,10 @@ int yolo_op_reorg(const float *x, int n, int h, int w, int c, int stride, int se
 int yolo_op_maxpool(const float *x, int n, int h, int w, int c, int size, int stride, float *out, int device);
 /* legacy-bilinear stretch of one uint8 image to [s,s,3] fp32: (value/255 then resize) * post_scale. */
 int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float post_scale, float *out, int device);
+/* V2/utils.py:13-27 `preprocess_image`'s arithmetic on the device: cv2.resize(float32 image, (ow, oh)) -- INTER_LINEAR, half-pixel centres,
+ * restated from OpenCV's published CV_32F linear resize -- of one uint8 [h,w,3] image, optionally after BGR -> RGB (swap_rb), then
+ * / divisor (the reference divides by 225.0, a typo kept).  out [oh,ow,3] fp32. */
+int yolo_op_resize_cv2(const uint8_t *img, int h, int w, int oh, int ow, int swap_rb, float divisor, float *out, int device);
 /* `detections_boxes` (V3/yolo_v3.py:329-347): (cx,cy,w,h,...) -> (x0,y0,x1,y1,...) over [n,rows,attrs] fp32 */
 int yolo_op_detections_boxes(const float *det, int n, int rows, int attrs, float *out, int device);
 /* head decode of raw [n,g,g,na*(5+classes)] fp32: yolo (logistic) or region (softmax) */

@@ -356,6 +356,33 @@ def resize_bilinear_legacy(img, out_h, out_w):
     return out[0] if squeeze else out
 
 
+def resize_cv2_linear(img, out_h, out_w):
+    """`cv2.resize(img_float32, (out_w, out_h))`, INTER_LINEAR, as V2/utils.py:19 calls it -- restated from OpenCV's published CV_32F linear
+    resize (imgproc/resize.cpp): half-pixel centres, fx = float32((dx + .5) * scale - .5) with scale = 1 / (dst / src) in double,
+    sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= src - 1 -> (src - 1, 0); a horizontal pass S[sx] * (1 - fx) + S[sx + 1] * fx, then the
+    vertical pass R0 * (1 - fy) + R1 * fy, float32 operations.  cv2 is not installed: PARITY UNPINNED (closed forms in
+    tests/test_oracle_closed_forms.py).  img [H,W,C] float32."""
+    img = np.asarray(img, dtype=np.float32); H, W = img.shape[:2]
+
+    def taps(n_out, n_in):
+        scale = 1.0 / (np.float64(n_out) / np.float64(n_in))
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64); f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0; f[lo] = 0; s[lo] = 0
+        hi = s >= n_in - 1; f[hi] = 0; s[hi] = n_in - 1
+        return s, np.minimum(s + 1, n_in - 1), (np.float32(1) - f).astype(np.float32), f
+    sx, sx1, a0, a1 = taps(out_w, W); sy, sy1, b0, b1 = taps(out_h, H)
+    a0 = a0[None, :, None]; a1 = a1[None, :, None]
+    rows = (img[:, sx] * a0 + img[:, sx1] * a1).astype(np.float32)                   # horizontal pass on every source row
+    return (rows[sy] * b0[:, None, None] + rows[sy1] * b1[:, None, None]).astype(np.float32)
+
+
+def v2_preprocess_image(image_bgr_u8, image_size=(416, 416)):
+    """V2/utils.py:13-27: float32 copy, BGR -> RGB, cv2.resize to image_size = (width, height), / 225.0 (sic), batch axis."""
+    x = np.asarray(image_bgr_u8).astype(np.float32)[:, :, ::-1]
+    return (resize_cv2_linear(x, image_size[1], image_size[0]) / np.float32(225.0))[None]
+
+
 def input_process(image_u8, size):
     """D2T/YOLO_V3_convert...py:106-111: uint8 HWC -> float /255.0 -> bilinear stretch -> [1,S,S,3]."""
     x = image_u8.astype(np.float32) / np.float32(255.0)

@@ -107,9 +107,12 @@ def test_yolo_v2_entry_points(hiplib):
     m = yolo_v2.Model(size=size, max_batch=1, dtype=hiplib.FP32, weights=flat)
     rng = np.random.default_rng(8)
     img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
-    x = yolo_v2.preprocess_image(img, (size, size))
-    want_x = R.resize_bilinear_legacy(img.astype(np.float32) / np.float32(255), size, size) * np.float32(255.0 / 225.0)
-    np.testing.assert_allclose(x[0], want_x, rtol=0, atol=2e-6)
+    x = yolo_v2.preprocess_image(img, (size, size))              # the reference's rule: BGR in, cv2.resize's half-pixel bilinear, / 225
+    assert np.array_equal(x, R.v2_preprocess_image(img, (size, size)))       # (same closed form, separately rounded float32 operations: bit for bit)
+    xr = yolo_v2.preprocess_image(img, (120, 72), bgr=False)     # dsize = (width, height); an RGB caller
+    assert xr.shape == (1, 72, 120, 3) and np.array_equal(xr[0], R.resize_cv2_linear(img.astype(np.float32), 72, 120) / np.float32(225.0))
+    xl = yolo_v2.preprocess_image(img, (size, size), legacy_tf_resize=True)  # rounds 1-5's rule, kept behind a flag
+    np.testing.assert_allclose(xl[0], R.resize_bilinear_legacy(img.astype(np.float32) / np.float32(255), size, size) * np.float32(255.0 / 225.0), rtol=0, atol=2e-6)
     g = size // 32
     raw = yolo_v2.build_network(x, model=m)                      # the reference's contract: the raw head (V2/model_darknet19_slim.py:198-200)
     assert raw.shape == (1, g, g, 425)

@@ -92,3 +92,32 @@ def test_bench_strong_scaling_and_parity_fields(hiplib, capsys, monkeypatch):
     assert out["value"] > 0 and abs(out["value"] - 8 * 1e3 / out["ms_per_step"]) / out["value"] < 0.01
     p = out["parity"]
     assert p["images"] == 1 and p["candidates"] > 20 and p["min_iou"] >= 0.99 and p["max_dscore"] <= 1e-2 and p["lost"] == 0
+
+
+def test_bench_two_ranks_one_gpu(hiplib, tmp_path):
+    """bench.py's rank > 0 branch on a real device.  The GPU boxes have ONE GPU, so two ranks are launched by the
+    contract's launcher (`python -m torch.distributed.run --nproc-per-node 2 ...`) with BENCH_BACKEND=gloo: both ranks compute on cuda:0,
+    the box records are exchanged through pinned host buffers by gloo (dist.HostStagedGather).  A FUNCTIONAL run -- shard bounds of a ragged
+    global batch (33 = 17 + 16), per-rank seeds, the pipelined exchange and its ordering, the MAX-reduce, the rank-0-only line --, not a
+    scaling measurement, and the line says so.  The launcher and its workers are child processes started before they touch the GPU (no exec
+    of a process that has initialised it)."""
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("torch does not see the GPU")
+    env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    port = str(32700 + os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--global-batch", "33", "--no-tune", "--no-cpu-baseline", "--parity-images", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                          # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 33
+    assert "17 image(s) on rank 0" in out["config"]["workload"] and out["config"]["per_rank"]["images_on_rank0"] == 17
+    assert out["value"] > 0 and abs(out["value"] - 33 * 1e3 / out["ms_per_step"]) / out["value"] < 0.01
+    assert out["backend"].startswith("gloo: FUNCTIONAL") and out["exchange_check"] is True
+

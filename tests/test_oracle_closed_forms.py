@@ -32,6 +32,28 @@ def test_resize_legacy_no_half_pixel():
     assert np.array_equal(R.resize_bilinear_legacy(x, 2, 2)[:, :, 0], x[::2, ::2, 0])
 
 
+def test_resize_cv2_half_pixel_rule():
+    """oracle.resize_cv2_linear (cv2.resize INTER_LINEAR on float32, V2/utils.py:19) against hand-derived cases of OpenCV's rule
+    (half-pixel centres, clamped borders; cv2 itself is absent: parity unpinned), and torch's align_corners=False bilinear, which uses
+    the same sample positions (an independent implementation; last-ulp differences from its other operation order allowed)."""
+    import torch
+    x = np.arange(12, dtype=np.float32).reshape(3, 4, 1)
+    assert np.array_equal(R.resize_cv2_linear(x, 3, 4), x)                        # same size: identity (fx == 0 everywhere)
+    up = R.resize_cv2_linear(x[:1, :2], 1, 4)[0, :, 0]                             # [0, 1] -> 4 samples at -0.25, 0.25, 0.75, 1.25
+    np.testing.assert_array_equal(up, np.array([0.0, 0.25, 0.75, 1.0], np.float32))
+    dn = R.resize_cv2_linear(x[:1], 1, 2)[0, :, 0]                                 # [0,1,2,3] -> samples at 0.5, 2.5
+    np.testing.assert_array_equal(dn, np.array([0.5, 2.5], np.float32))
+    rng = np.random.default_rng(0)
+    img = rng.random((37, 53, 3), dtype=np.float32) * 255
+    for oh, ow in ((416, 416), (20, 31), (64, 40)):
+        got = R.resize_cv2_linear(img, oh, ow)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 * 255)
+    bgr = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    out = R.v2_preprocess_image(bgr, (11, 9))
+    assert out.shape == (1, 9, 11, 3) and np.array_equal(out[0], bgr[:, :, ::-1].astype(np.float32) / np.float32(225.0))   # BGR -> RGB, the 225 typo
+
+
 def test_space_to_depth_index_map():
     x = np.arange(1 * 4 * 4 * 4, dtype=np.float32).reshape(1, 4, 4, 4)
     y = R.space_to_depth(x, 2)

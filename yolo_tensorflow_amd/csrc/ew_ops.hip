@@ -175,6 +175,43 @@ hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *o
     return hipGetLastError();
 }
 
+// `cv2.resize(image_float32, (ow, oh))` as V2/utils.py:13-27 calls it (INTER_LINEAR on a float32 image, after BGR -> RGB) followed by the
+// reference's `/ 225.0` -- restated from OpenCV's published resize (imgproc/resize.cpp, the CV_32F linear path): half-pixel centres,
+//   fx = (float)((dx + 0.5) * (double)(src_w / dst_w as 1 / (dst_w / src_w)) - 0.5); sx = floor(fx); fx -= sx;
+//   sx < 0 -> (sx, fx) = (0, 0);  sx >= src_w - 1 -> (sx, fx) = (src_w - 1, 0);     likewise in y,
+// a horizontal pass S[sx] * (1 - fx) + S[sx + 1] * fx on both rows, then the vertical one R0 * (1 - fy) + R1 * fy (separately rounded
+// float operations: this file is compiled with -ffp-contract=off).  cv2 is absent here: parity unpinned, oracle.resize_cv2_linear is the
+// same closed form.  swap_rb: output channel c reads input channel 2 - c (cv2.cvtColor(..., COLOR_BGR2RGB)).
+__global__ void k_resize_cv2_u8(const uint8_t *img, int h, int w, int oh, int ow, int swap_rb, float divisor, float *out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= oh * ow) return;
+    const int dy = p / ow, dx = p - dy * ow;
+    const double scale_x = 1.0 / ((double)ow / (double)w), scale_y = 1.0 / ((double)oh / (double)h);
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5), fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= w - 1) { sx = w - 1; fx = 0.f; }
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    if (sy >= h - 1) { sy = h - 1; fy = 0.f; }
+    const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ci = swap_rb ? 2 - c : c;
+        const float p00 = (float)img[((size_t)sy * w + sx) * 3 + ci], p01 = (float)img[((size_t)sy * w + sx1) * 3 + ci];
+        const float p10 = (float)img[((size_t)sy1 * w + sx) * 3 + ci], p11 = (float)img[((size_t)sy1 * w + sx1) * 3 + ci];
+        const float r0 = p00 * a0 + p01 * a1, r1 = p10 * a0 + p11 * a1;
+        out[(size_t)p * 3 + c] = (r0 * b0 + r1 * b1) / divisor;
+    }
+}
+hipError_t launch_resize_cv2_u8(const uint8_t *img, int h, int w, int oh, int ow, int swap_rb, float divisor, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_resize_cv2_u8, grid_for((size_t)oh * ow), dim3(256), 0, s, img, h, w, oh, ow, swap_rb, divisor, out);
+    return hipGetLastError();
+}
+
 // ---- row U: 2x upsample.  bilinear = closed form of pad(SYMMETRIC 1) -> legacy resize_bilinear -> crop,
 //      evaluated with TF's lerp order (x then y, a + (b-a)*t, t in {0, .5}); else nearest (darknet). ----
 template <typename T>

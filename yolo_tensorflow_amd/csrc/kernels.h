@@ -197,6 +197,8 @@ hipError_t launch_preprocess(const void *img, int fmt /*0 u8, 1 f32*/, int n, in
                              void *out, int out_dt, int out_stride, hipStream_t s, float post_mul = 1.0f, float post_add = 0.0f);
 hipError_t launch_resize_u8(const uint8_t *img, int h, int w, int s_out, void *out, int out_dt,
                             int out_stride, int out_c, hipStream_t s, float post_scale = 1.0f, float post_add = 0.0f);
+// cv2.resize (INTER_LINEAR, float32) of a uint8 [h,w,3] image to fp32 [oh,ow,3], optional BGR -> RGB, then / divisor (V2/utils.py:13-27)
+hipError_t launch_resize_cv2_u8(const uint8_t *img, int h, int w, int oh, int ow, int swap_rb, float divisor, float *out, hipStream_t s);
 hipError_t launch_upsample2x(const TView &in, const TView &out, int bilinear, hipStream_t s);
 hipError_t launch_maxpool(const TView &in, const TView &out, int size, int stride, int pad, hipStream_t s);
 hipError_t launch_reorg(const TView &in, const TView &out, int stride, int darknet, hipStream_t s);

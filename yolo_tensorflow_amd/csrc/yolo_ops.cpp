@@ -199,6 +199,16 @@ int yolo_op_resize_u8(const uint8_t *img, int h, int w, int s, float post_scale,
     return S.download(out, d_o, (size_t)s * s * 3 * 4);
 }
 
+int yolo_op_resize_cv2(const uint8_t *img, int h, int w, int oh, int ow, int swap_rb, float divisor, float *out, int device)
+{
+    if (!img || !out || h < 1 || w < 1 || oh < 1 || ow < 1 || !(divisor != 0.f)) { g_op_err = "resize_cv2: bad arguments"; return YOLO_ERR_INVALID; }
+    OpScope S(device); if (S.rc) return S.rc;
+    uint8_t *d_i = (uint8_t *)S.upload(img, (size_t)h * w * 3); float *d_o = (float *)S.alloc((size_t)oh * ow * 3 * 4);
+    if (S.rc) return S.rc;
+    if (!S.ok(launch_resize_cv2_u8(d_i, h, w, oh, ow, swap_rb, divisor, d_o, S.s))) { g_op_err = S.err; return S.rc; }
+    return S.download(out, d_o, (size_t)oh * ow * 3 * 4);
+}
+
 int yolo_op_letterbox(const float *image_chw, int iw, int ih, int w, int h, int embed, float *out_chw, int device)
 {
     if (!image_chw || !out_chw || iw < 1 || ih < 1 || w < 1 || h < 1) { g_op_err = "letterbox: bad arguments"; return YOLO_ERR_INVALID; }

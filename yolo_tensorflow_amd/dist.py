@@ -131,6 +131,55 @@ class PipelinedGather(object):
         return self.out[k]
 
 
+class HostStagedGather(object):
+    """PipelinedGather's interface for a process group WITHOUT device collectives (backend "gloo": bench.py's functional multi-rank mode, two
+    or more ranks sharing one GPU, BENCH_BACKEND=gloo): step n's records are copied device -> pinned host on the current stream, and the
+    collective -- `all_gather` of the host buffers -- is started one submit later, when that copy has long completed, and waited for at the
+    submit after that (or by `result()`).  Same double buffering, same one-step-behind contract; `result()` returns a HOST tensor."""
+
+    def __init__(self, rec, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.stage = [torch.empty(rec.shape, dtype=rec.dtype).pin_memory() if rec.is_cuda else torch.empty_like(rec) for _ in range(2)]
+        self.out = [torch.empty((self.world, rec.numel()), dtype=rec.dtype) for _ in range(2)]
+        self.copied = [torch.cuda.Event() if rec.is_cuda else None for _ in range(2)]
+        self.state = [0, 0]       # 0 free, 1 copy enqueued, 2 collective in flight
+        self.work = [None, None]
+        self.k = 0; self.last = None
+
+    def _start(self, k):
+        import torch.distributed as dist
+        if self.state[k] == 1:
+            if self.copied[k] is not None:
+                self.copied[k].synchronize()
+            self.work[k] = dist.all_gather([self.out[k][r] for r in range(self.world)], self.stage[k], group=self.group, async_op=True)
+            self.state[k] = 2
+
+    def _finish(self, k):
+        self._start(k)
+        if self.state[k] == 2:
+            self.work[k].wait(); self.work[k] = None; self.state[k] = 0
+
+    def submit(self, rec):
+        k = self.k
+        self._finish(k)                     # the exchange that used this pair two submits ago
+        if self.last is not None:
+            self._start(self.last)          # the previous step's copy is done by now: its collective runs under this step
+        self.stage[k].copy_(rec, non_blocking=True)
+        if self.copied[k] is not None:
+            self.copied[k].record()
+        self.state[k] = 1
+        self.last = k; self.k = 1 - k
+
+    def result(self):
+        if self.last is None:
+            return None
+        self._finish(1 - self.last); self._finish(self.last)
+        return self.out[self.last]
+
+
 def split_flat_records(rec_all, n_local, max_out):
     """[world, flat] -> (boxes [world*n_local, max_out*6], counts [world*n_local]) in rank (= image) order."""
     world = rec_all.shape[0]

@@ -33,7 +33,7 @@ EXPORTS = [
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_darknet_boxes", "yolo_last_layer_size", "yolo_last_layer_output", "yolo_op_letterbox",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
-    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw", "yolo_calibrate",
+    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw", "yolo_calibrate", "yolo_op_resize_cv2",
 ]
 # include/yolo_dist.h: the image-sharded detect step
 DIST_EXPORTS = ["yolo_shard_bounds", "yolo_dist_flat_words", "yolo_dist_split_records", "yolo_dist_unique_id", "yolo_dist_create",
@@ -110,6 +110,7 @@ def load_library():
     l.yolo_last_layer_output_batch.argtypes = [P, I, P, C.c_size_t]
     l.yolo_head_raw.argtypes = [P, I, I, P, C.c_size_t]
     l.yolo_calibrate.argtypes = [I, P, I, C.c_double, FP, FP]
+    l.yolo_op_resize_cv2.argtypes = [P, I, I, I, I, I, F, P, I]
     l.yolo_shard_bounds.argtypes = [I, I, I, C.POINTER(I), C.POINTER(I)]
     l.yolo_dist_flat_words.argtypes = [I, I]; l.yolo_dist_flat_words.restype = C.c_size_t
     l.yolo_dist_split_records.argtypes = [P, I, I, I, P, P]
@@ -445,6 +446,15 @@ def op_resize_u8(img, size, post_scale=1.0, device=0):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     out = np.empty((size, size, 3), dtype=np.float32)
     _op_check(load_library().yolo_op_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], size, post_scale, out.ctypes.data, device), "yolo_op_resize_u8")
+    return out
+
+
+def op_resize_cv2(img, out_hw, swap_rb=True, divisor=225.0, device=0):
+    """yolo_op_resize_cv2: `cv2.resize(image.astype(float32)[, BGR -> RGB], (w, h)) / divisor` of one uint8 [h,w,3] image -> [oh,ow,3] float32."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((int(out_hw[0]), int(out_hw[1]), 3), dtype=np.float32)
+    _op_check(load_library().yolo_op_resize_cv2(img.ctypes.data, img.shape[0], img.shape[1], int(out_hw[0]), int(out_hw[1]), 1 if swap_rb else 0,
+                                                float(divisor), out.ctypes.data, device), "yolo_op_resize_cv2")
     return out
 
 

@@ -23,13 +23,21 @@ class Model:
         self.engine.close()
 
 
-def preprocess_image(image, image_size=(416, 416)):
-    """V2/utils.py:13-27 minus OpenCV: expects an RGB uint8 image, stretches it with the legacy bilinear rule on the
-    device and returns [1,H,W,3] float32.  NB the reference divides by 225.0 (a typo, :22); reproduced."""
-    if image_size[0] != image_size[1]:
-        raise hip.YoloError("square network input only")
-    # (value/255 -> legacy bilinear) * 255/225 on the device == resize(value)/225 up to rounding
-    return hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0], post_scale=255.0 / 225.0)[None]
+def preprocess_image(image, image_size=(416, 416), bgr=True, legacy_tf_resize=False):
+    """V2/utils.py:13-27, same arguments: `image` is what the reference's callers pass -- the uint8 [H,W,3] array of `cv2.imread`, i.e. BGR
+    (V2/Main.py, V2/YOLO_v2.py:49-52) -- and the result is [1, h, w, 3] float32 = cv2.resize(float32(image) as RGB, image_size) / 225.0:
+    the colour swap (`cv2.cvtColor(.., COLOR_BGR2RGB)`), OpenCV's INTER_LINEAR rule (half-pixel centres) and the reference's 225.0 (a typo
+    for 255, :22; reproduced) all on the device (`yolo_op_resize_cv2`).  image_size is cv2's dsize = (width, height).
+    bgr=False: the image is already RGB (PIL / the other modules of this package) -- no swap.
+    legacy_tf_resize=True: rounds 1-5's behaviour (TF's legacy bilinear rule, RGB input), what the V3 graph's `_input_process` uses; kept for
+    callers that relied on it.  OpenCV is not installed here: the rule is restated from its published source and checked against the
+    oracle's closed form (`oracle.resize_cv2_linear`), not against cv2 itself."""
+    if legacy_tf_resize:
+        if image_size[0] != image_size[1]:
+            raise hip.YoloError("legacy rule: square network input only")
+        # (value/255 -> legacy bilinear) * 255/225 on the device == resize(value)/225 up to rounding
+        return hip.op_resize_u8(np.ascontiguousarray(image, dtype=np.uint8), image_size[0], post_scale=255.0 / 225.0)[None]
+    return hip.op_resize_cv2(image, (image_size[1], image_size[0]), swap_rb=bgr, divisor=225.0)[None]
 
 
 def build_network(images, num_outputs=425, alpha=0.1, keep_prob=0.5, is_training=False, scope='yolov2', model=None, fused=False):
