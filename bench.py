@@ -102,13 +102,14 @@ def tolerance_line(hip, IO, base_cfg_txt, flat, args, dev, stream, images, refs,
     """The configuration that MEETS north_star's tolerance (decoded boxes within IoU >= 0.999 of the fp32 reference), timed in the same process
     on the same resident batch, after and outside the headline's timed region.  bf16 -- BASELINE's named type, the
     headline -- has an 8-bit significand and cannot hold 0.999 (1 - IoU falls 4-5 x per 2 bits, 0.999 needs 13-17); this
-    leg is the fastest configuration of the library that does on every weight flavour of tests/test_gpu_tolerance.py: split-fp16 pairs
+    leg is the fastest configuration of the library that does on every weight flavour of tests/test_gpu_fp16x2.py (benign, drawn and real
+    trained-file statistics) and on all 32 images of this batch (tests/test_gpu_tuned.py): split-fp16 pairs
     (22 significant bits, W_hi x_hi + W_hi x_lo + W_lo x_hi on the fp16 MFMA = 3 MFMA products per algorithmic product, fp32 accumulation).
     Same step (uint8 batch resident in HBM -> conv stack -> decode -> threshold -> TF-NMS), same graph replay, same event timing."""
     import torch
     from yolo_tensorflow_amd import dist as ydist
     B = int(images.shape[0]); max_out = 20
-    cfg_txt = base_cfg_txt; products = 3.0; what = "split fp16 pairs (hi + lo) on every tensor and filter"
+    cfg_txt = base_cfg_txt; products = 3.0; what = "split fp16 pairs (hi + lo, interleaved per 32-channel group) on every tensor and filter; pair K loop: W_hi x_hi + W_lo x_hi + W_hi x_lo per K-step row pair"
     eng = hip.Engine(cfg_txt, max_batch=B, dtype=hip.FP16X2, semantics=hip.SEM_TF, decode=hip.DECODE_RATIO, device=dev.index, stream=stream.cuda_stream)
     try:
         eng.set_weights(flat)

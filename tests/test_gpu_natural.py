@@ -103,9 +103,11 @@ _CASES = [pytest.param(st, dt, marks=pytest.mark.xfail(strict=True, reason="e4m3
                                                                           "0.00 at batch 32 with 8 892 of 19 411 candidates lost; no e4m3 plan exists there (DESIGN.md section 4)"))
           if (dt == "fp8" and st == "log") else pytest.param(st, dt)
           for st in ("benign", "log", "real") for dt in ("fp32", "bf16", "fp8")]
-# measured floors (printed by the test; DESIGN.md section 4 quotes them): guards sit just under the measured values
-BF16_FLOOR = {"log": (0.60, 0.20), "real": (0.975, 0.01)}         # (min IoU, max |dscore|): measured 0.65 / 0.17; real, the five ordinary jpgs (real_split): 0.9843 / 0.0078
-FP8_FLOOR = {"benign": (0.70, 0.06), "real": (0.80, 0.45)}         # measured 0.76 / 0.040; real, the five ordinary jpgs: 0.836 / 0.397 (384 of 1 672 candidates lost)
+# REGRESSION GUARDS, not tolerances: they sit just under the measured values (printed by the test; DESIGN.md section 4 quotes them) so that a
+# change which makes a 16-bit / e4m3 row worse is noticed.  north_star's tolerance is IoU >= 0.999; every row prints whether it meets it, and the
+# rows that are ASSERTED at 0.999 are fp32 here and the split-fp16 pairs in test_gpu_fp16x2.py / test_gpu_tuned.py (the tolerance line).
+BF16_REGRESSION_GUARD = {"log": (0.60, 0.20), "real": (0.975, 0.01)}         # (min IoU, max |dscore|): measured 0.65 / 0.17; real, the five ordinary jpgs (real_split): 0.9843 / 0.0078
+FP8_REGRESSION_GUARD = {"benign": (0.70, 0.06), "real": (0.80, 0.45)}         # measured 0.76 / 0.040; real, the five ordinary jpgs: 0.836 / 0.397 (384 of 1 672 candidates lost)
 
 
 @pytest.mark.parametrize("stats,dtype_name", _CASES)
@@ -119,8 +121,8 @@ def test_reference_images_through_the_detector(hiplib, stats, dtype_name):
     det = np.stack([d.engine.forward_image(_load(p))[0] for p in IMAGES])
     margin = {"fp32": 1e-3, "bf16": 1e-2, "fp8": 0.0}[dtype_name]
     miou, mds, cnt, lost = box_deviation(ref, det, margin, thr=thr)
-    print("natural images, %s weights, %s: %d candidates over %d images, min IoU %.4f, max |dscore| %.5f, below threshold %d"
-          % (stats, dtype_name, cnt, len(IMAGES), miou, mds, lost))
+    print("natural images, %s weights, %s: %d candidates over %d images, min IoU %.4f, max |dscore| %.5f, below threshold %d -> meets north_star 0.999: %s%s"
+          % (stats, dtype_name, cnt, len(IMAGES), miou, mds, lost, "yes" if miou >= 0.999 and lost == 0 else "no", "" if dtype_name == "fp32" else " (asserted below: a regression guard)"))
     assert cnt >= 20
     if stats == "real":
         (miou, mds, cnt, lost), hard = real_split(ref, det, margin, thr)
@@ -157,9 +159,9 @@ def test_reference_images_through_the_detector(hiplib, stats, dtype_name):
         e = box_deviation(np.stack(emu), det[:2], 1e-2, thr=thr)
         print("   ... device vs the oracle's bf16-storage emulation (2 images): %d candidates, min IoU %.4f, max |dscore| %.5f, lost %d" % (e[2], e[0], e[1], e[3]))
         assert e[0] >= 0.85 and e[1] <= 0.1            # (log: measured 0.904 / 0.073: the same amplification acts on the summation-order differences)
-        assert miou >= BF16_FLOOR[stats][0] and mds <= BF16_FLOOR[stats][1]
+        assert miou >= BF16_REGRESSION_GUARD[stats][0] and mds <= BF16_REGRESSION_GUARD[stats][1]
     else:
-        lo, hi = FP8_FLOOR.get(stats, (0.5, 0.2))      # (log: the strict-xfail row -- this floor is what it is expected to miss)
+        lo, hi = FP8_REGRESSION_GUARD.get(stats, (0.5, 0.2))      # (log: the strict-xfail row -- this floor is what it is expected to miss)
         assert np.isfinite(det).all() and miou >= lo and mds <= hi
     d.engine.close()
 
@@ -186,10 +188,10 @@ PLANS = os.path.join(os.path.dirname(ROOT), "yolo_tensorflow_amd", "tuned")
 # reference's own vectors (round 5)
 # (the `real` stand-in on NOISE images is in its amplifying regime throughout -- 42 611 candidates against 18 744 on `log` --, like person.jpg
 #  among the natural ones: bf16 measured 0.056 / 0.52 with 3 338 candidates lost)
-FLOOR32 = {("log", "bf16"): (0.48, 0.30), ("log", "fp16"): (0.90, 0.04), ("real", "bf16"): (0.04, 0.60), ("real", "fp16"): (0.65, 0.13)}       # (real: measured 0.056 / 0.52 and 0.698 / 0.110, 198 lost)
+REGRESSION_GUARD32 = {("log", "bf16"): (0.48, 0.30), ("log", "fp16"): (0.90, 0.04), ("real", "bf16"): (0.04, 0.60), ("real", "fp16"): (0.65, 0.13)}       # (real: measured 0.056 / 0.52 and 0.698 / 0.110, 198 lost)
 
 
-@pytest.mark.parametrize("stats", ["log", "real"])
+@pytest.mark.parametrize("stats", ["log", "real"], ids=["log-regression_guard", "real-regression_guard"])
 def test_trained_statistics_32_images_bf16_and_fp16(hiplib, stats):
     """DESIGN section 4's 32-image table on weights with trained-file batch-norm statistics (416 x 416, batch 32, the committed tile
     plans): bf16 and fp16 storage against the fp32 oracle; the bits law in two rows (three more significand bits)."""
@@ -201,10 +203,11 @@ def test_trained_statistics_32_images_bf16_and_fp16(hiplib, stats):
         eng.set_weights(flat); eng.set_tile_configs(json.load(open(os.path.join(PLANS, "yolov3_416_b32_bf16.json")))["cfgs"])
         det = eng.forward(img); eng.close()
         m = box_deviation(ref, det, 1e-2)
-        print("%s-statistics weights, %s 416 b32 vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.5f, lost %d" % (stats, name, m[2], m[0], m[1], m[3]))
+        print("%s-statistics weights, %s 416 b32 vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.5f, lost %d -> meets north_star 0.999: %s (asserted: regression guard %s)"
+              % (stats, name, m[2], m[0], m[1], m[3], "yes" if m[0] >= 0.999 and m[3] == 0 else "no", REGRESSION_GUARD32[(stats, name)]))
         got[name] = m
     for name, m in got.items():
-        lo, hi = FLOOR32[(stats, name)]
+        lo, hi = REGRESSION_GUARD32[(stats, name)]
         assert m[2] > 100 and m[0] >= lo and m[1] <= hi, (name, m)
     assert got["fp16"][0] > got["bf16"][0] and got["fp16"][3] < got["bf16"][3]
 
@@ -215,7 +218,7 @@ _E4M3_32 = [pytest.param(st, kind, marks=pytest.mark.xfail(strict=True, reason="
             pytest.param(st, kind, marks=pytest.mark.xfail(strict=True, reason="e4m3 storage on the reference's real batch-norm vectors, noise images (the stand-in's amplifying regime): measured min IoU "
                                                                                  "0.00, 8 660 (mixed plan) to 17 839 (e4m3 everywhere) of 43 547 candidates lost; bf16 itself is at 0.056 there"))
             for st in ("log", "real") for kind in ("mixed", "unit", "calibrated")]
-FLOOR32_E4M3 = {"mixed": (0.85, 0.08), "unit": (0.30, 0.40), "calibrated": (0.30, 0.40)}      # what a usable e4m3 configuration would have to hold: every row is expected to miss it
+E4M3_USABILITY_BAR32 = {"mixed": (0.85, 0.08), "unit": (0.30, 0.40), "calibrated": (0.30, 0.40)}      # what a usable e4m3 configuration would have to hold: every row is expected to miss it
 
 
 @pytest.mark.parametrize("stats,kind", _E4M3_32)
@@ -239,5 +242,5 @@ def test_trained_statistics_32_images_e4m3(hiplib, stats, kind):
     det = eng.forward(img); eng.close()
     m = box_deviation(ref, det, 0.0)
     print("%s-statistics weights, e4m3 (%s) 416 b32 vs fp32 oracle: %d candidates, min IoU %.4f, max |dscore| %.4f, below threshold %d" % (stats, kind, m[2], m[0], m[1], m[3]))
-    lo, hi = FLOOR32_E4M3[kind]
+    lo, hi = E4M3_USABILITY_BAR32[kind]
     assert np.isfinite(det).all() and m[0] >= lo and m[1] <= hi

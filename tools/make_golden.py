@@ -509,10 +509,28 @@ def gen_bn_real():
                  min(c["var"].min() for c in bn), max(c["var"].max() for c in bn)))
 
 
+def gen_known_answers():
+    """The reference's only recorded END-TO-END results: the detections its darknet binding printed for dog.jpg with the genuine
+    yolov2.weights (D2T/log.txt:223) and yolov3.weights (:950) -- `detect()` of D2T/darknet.py:125-142, thresh .5, nms .45: a list of
+    (class name, probability, (cx, cy, w, h) in pixels of the 768 x 576 image).  Numbers only -> tests/golden/dog_known_answers.json; they
+    become checkable the day somebody supplies the files (tests/test_gpu_real_weights.py, YOLO_REAL_WEIGHTS / YOLO_REAL_WEIGHTS_V2)."""
+    import ast, json
+    lines = open(os.path.join(REF, "Darknet2Tensorflow", "darknet-master", "log.txt")).read().split("\n")
+    out = {"image": "dog.jpg", "image_size_wh": [768, 576], "call": "darknet.py detect(net, meta, image, thresh=.5, hier_thresh=.5, nms=.45)",
+           "coco_index": {"bicycle": 1, "truck": 7, "dog": 16}}
+    for name, ln in (("yolov2", 223), ("yolov3", 950)):
+        dets = ast.literal_eval(lines[ln - 1])
+        out[name] = {"log_line": ln, "detections": [{"name": n, "prob": p, "box_cxcywh": list(b)} for n, p, b in dets]}
+        print(name, [(n, round(p, 4)) for n, p, _ in dets])
+    json.dump(out, open(os.path.join(OUT, "dog_known_answers.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["bn_real"]:
         gen_bn_real(); sys.exit(0)
+    if sys.argv[1:] == ["known_answers"]:
+        gen_known_answers(); sys.exit(0)
     stub_modules()
     gen_nms_v3()
     gen_v2_post()
@@ -521,3 +539,4 @@ if __name__ == "__main__":
     gen_mini_v1()
     gen_mini_local()
     gen_bn_real()
+    gen_known_answers()
