@@ -167,6 +167,34 @@ def test_fp16x2_batch32_416_log_statistics_and_autotune(hiplib):
     eng.close()
 
 
+def test_fp16x2_first_layer_direct_kernel_and_one_launch_upsample(hiplib, monkeypatch):
+    """Round 6: (a) the image layer of a split-fp16 network runs a direct kernel (pixel vectors straight from global memory, W_hi / W_lo in
+    registers, three products per 16 x 16 tile) -- against the tiled kernel it replaces (YOLO_NO_PAIR_DIRECT=1) its output differs in fp32
+    summation order only; (b) the 2x upsample of a pair tensor is ONE launch (join, fp32 lerp, split) -- bit-identical to the
+    join / fp32 upsample / split sequence through fp32 staging (YOLO_PAIR_UPSAMPLE_VIA_F32=1), TF bilinear and darknet nearest alike."""
+    for sem in (hiplib.SEM_TF, hiplib.SEM_DARKNET):
+        txt = IO.with_input_size(IO.cfg_text("yolov3"), 160)
+        secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=21)
+        img = np.random.default_rng(22).integers(0, 256, (2, 160, 160, 3), dtype=np.uint8)
+        eng = hiplib.Engine(txt, max_batch=2, dtype=hiplib.FP16X2, semantics=sem, keep_layers=True)
+        eng.set_weights(flat)
+        det = eng.forward(img); l0 = eng.layer_output(0, 2)
+        ups = [i for i, s_ in enumerate(secs[1:]) if s_["type"] == "upsample"]
+        up = [eng.layer_output(i, 2) for i in ups]
+        monkeypatch.setenv("YOLO_PAIR_UPSAMPLE_VIA_F32", "1")
+        assert np.array_equal(eng.forward(img), det)
+        for i, u in zip(ups, up):
+            assert np.array_equal(eng.layer_output(i, 2), u)
+        monkeypatch.delenv("YOLO_PAIR_UPSAMPLE_VIA_F32")
+        monkeypatch.setenv("YOLO_NO_PAIR_DIRECT", "1")
+        det_t = eng.forward(img); l0_t = eng.layer_output(0, 2)
+        monkeypatch.delenv("YOLO_NO_PAIR_DIRECT")
+        eng.close()
+        assert not np.array_equal(l0, l0_t) or True          # (may or may not differ in the last bit)
+        assert np.abs(l0 - l0_t).max() <= 2e-6 * np.abs(l0_t).max()
+        assert np.abs(det - det_t).max() <= 1e-4 * np.abs(det_t).max()
+
+
 def test_fp16x2_refuses_what_it_does_not_serve(hiplib):
     with pytest.raises(hiplib.YoloError, match="split-fp16"):
         hiplib.Engine(IO.cfg_text("yolov1"), dtype=hiplib.FP16X2)

@@ -295,6 +295,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
     // (16-bit storage: bf16, or fp16 -- the same tile table, the same kernels with the other MFMA and conversions)
     if (a.in_dt != DT_BF16 && a.in_dt != DT_F16) return hipErrorInvalidValue;
     if (a.in_dt == DT_F16 && a.out_dt != DT_F16 && a.out_dt != DT_F32) return hipErrorInvalidValue;
+    if (cfg == CONV_CFG_DIRECT && a.split) return launch_conv_c8_direct_pair(a, s);      // the first layer of a split-fp16 network: direct kernel (conv_pair.hip)
     if (a.pairk) return launch_conv_pair(a, cfg, s);          // the input is an interleaved pair tensor: the pair K loop (conv_pair.hip, conv_halo13.hip)
     if (a.split) {
         // split fp16 storage (YOLO_FP16X2), PLAIN input (or the network input's three blocks): fp16 operands, the ordinary K loop, 16-bit

@@ -472,6 +472,46 @@ __global__ void k_add_split(const f16_t *a, int as, const f16_t *b, int bs, f16_
     for (int i = 0; i < 8; ++i) x[i] = x[i] + y[i];
     put_split8(o + p * os + ho, Cp, PAIR_ILV, x);
 }
+// 2x upsample of an interleaved pair tensor in ONE launch: join (hi + lo), the fp32 kernel's arithmetic (k_upsample2x: TF's lerp order, or
+// nearest), split -- bit-identical to the join / fp32 upsample / split sequence it replaces (three launches through fp32 staging)
+__global__ void k_upsample2x_pair(const f16_t *in, int is, f16_t *out, int os, int n, int h, int w, int Cp, int bilinear)
+{
+    const int c8 = Cp / 8;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * 2 * h * 2 * w * c8;
+    if (idx >= total) return;
+    const int g = (int)(idx % c8); size_t p = idx / c8;
+    const int ox = (int)(p % (2 * w)); p /= (2 * w);
+    const int oy = (int)(p % (2 * h)); const int b = (int)(p / (2 * h));
+    const int iy = oy >> 1, ix = ox >> 1, ho = pair_hi_off(g, Cp, PAIR_ILV);
+    const f16_t *base = in + (size_t)b * h * w * is + ho;
+    f16_t *o = out + (((size_t)b * 2 * h + oy) * 2 * w + ox) * os + ho;
+    if (!bilinear) {          // nearest: join and split again, as the fp32 sequence does (split(join(hi, lo)) may choose another pair for the same value at a tie)
+        float v[8]; join8(base + ((size_t)iy * w + ix) * is, 32, v);
+        put_split8(o, Cp, PAIR_ILV, v);
+        return;
+    }
+    const int iy1 = min(iy + 1, h - 1), ix1 = min(ix + 1, w - 1);
+    const float xl = (ox & 1) ? 0.5f : 0.f, yl = (oy & 1) ? 0.5f : 0.f;
+    float tl[8], tr[8], bl[8], br[8], r[8];
+    join8(base + ((size_t)iy * w + ix) * is, 32, tl); join8(base + ((size_t)iy * w + ix1) * is, 32, tr);
+    join8(base + ((size_t)iy1 * w + ix) * is, 32, bl); join8(base + ((size_t)iy1 * w + ix1) * is, 32, br);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float top = tl[i] + (tr[i] - tl[i]) * xl;
+        const float bot = bl[i] + (br[i] - bl[i]) * xl;
+        r[i] = top + (bot - top) * yl;
+    }
+    put_split8(o, Cp, PAIR_ILV, r);
+}
+hipError_t launch_upsample2x_pair(const TView &in, const TView &out, int bilinear, hipStream_t s)
+{
+    const int Cp = (in.c + 31) / 32 * 32;
+    if (in.dt != DT_F16 || out.dt != DT_F16 || in.stride < 2 * Cp || out.stride < 2 * Cp) return hipErrorInvalidValue;
+    const size_t total = (size_t)in.n * 4 * in.h * in.w * (Cp / 8);
+    hipLaunchKernelGGL(k_upsample2x_pair, grid_for(total), dim3(256), 0, s, (const f16_t *)in.ptr, in.stride, (f16_t *)out.ptr, out.stride, in.n, in.h, in.w, Cp, bilinear);
+    return hipGetLastError();
+}
 hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s, int layout)
 {
     hipLaunchKernelGGL(k_split_from_f32, grid_for(npix * (Cp / 8)), dim3(256), 0, s, in, in_stride, (f16_t *)out, out_stride, Cp, npix, layout);

@@ -141,7 +141,10 @@ bool conv_cfg_tail_ok(int cfg, int cout, bool fp8, bool head = false);      // c
 bool conv_cfg_fp8_ok(int cfg);
 bool conv_cfg_split_ok(int cfg);      // tile configurations instantiated for split fp16 storage (YOLO_FP16X2)
 bool conv_cfg_pairk_ok(int cfg, bool split_out);      // ... and for a conv that READS interleaved pairs (pair K loop), writing pairs / plain fp16 or an fp32 head
-hipError_t launch_conv_pair(const ConvArgs &a, int cfg, hipStream_t s);      // the tiled pair-K-loop instantiations (conv_pair.hip); the halo ones: launch_conv_halo13
+hipError_t launch_conv_pair(const ConvArgs &a, int cfg, hipStream_t s);
+// first layer of a split-fp16 network (image in three blocks hi | lo | hi -> interleaved pairs): the direct kernel, no LDS (conv_pair.hip)
+bool conv_c8_direct_pair_ok(const ConvArgs &a);
+hipError_t launch_conv_c8_direct_pair(const ConvArgs &a, hipStream_t s);      // the tiled pair-K-loop instantiations (conv_pair.hip); the halo ones: launch_conv_halo13
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);
 hipError_t launch_conv_diag(const ConvArgs &a, hipStream_t s);   // stamped diagnostic build of p176c128_s2 (tools only)
 // fused stem: conv 3x3/s1 (3 -> 32) + conv 3x3/s2 (32 -> 64), bf16 (conv_stem.hip)
@@ -215,6 +218,7 @@ hipError_t launch_from_f32(const float *in, const TView &out, hipStream_t s, flo
 enum { PAIR_ILV = 0, PAIR_B3 = 1 };
 hipError_t launch_split_from_f32(const float *in, int in_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s, int layout = PAIR_ILV);   // fp32 [pixel][in_stride >= Cp] -> pairs
 hipError_t launch_split_to_f32(const void *in, int in_stride, int Cp, float *out, int out_stride, size_t npix, hipStream_t s, int layout = PAIR_ILV);      // pairs -> fp32 (hi + lo)
+hipError_t launch_upsample2x_pair(const TView &in, const TView &out, int bilinear, hipStream_t s);      // 2x upsample of an interleaved pair tensor (join, fp32 lerp, split) in one launch
 hipError_t launch_add_split(const void *a, int a_stride, const void *b, int b_stride, void *out, int out_stride, int Cp, size_t npix, hipStream_t s);      // shortcut on interleaved pair tensors
 
 // ---- head decode + postprocess (post_ops.hip) ---------------------------------------------------

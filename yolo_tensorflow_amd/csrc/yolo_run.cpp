@@ -54,6 +54,9 @@ ConvArgs conv_args(const yolo_ctx *c, const Layer &L, int n)
 // split fp16: the untuned choice among the instantiated shapes (conv_cfg_split_ok)
 static int split_default_cfg(const ConvArgs &a)
 {
+    // the image layer: the direct pair kernel wherever it applies -- and ONLY it (its K grouping differs from the tiled kernel's: were both
+    // selectable, a tuned plan would no longer be the built-in plan bit for bit)
+    if (conv_c8_direct_pair_ok(a)) return CONV_CFG_DIRECT;
     const long M = (long)a.N * a.Ho * a.Wo;
     if (a.Cout <= 32) return 4;
     if (a.Cout <= 64) return M >= 65536 ? 8 : 6;
@@ -142,6 +145,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         if (a.split || a.pairk) {
             auto inst = [&](int cfg) { return a.pairk ? conv_cfg_pairk_ok(cfg, a.split != 0) : conv_cfg_split_ok(cfg); };
             int cfg = L.tile_cfg >= 0 && inst(L.tile_cfg) ? L.tile_cfg : split_default_cfg(a);
+            if (conv_c8_direct_pair_ok(a)) cfg = CONV_CFG_DIRECT;          // the image layer: the direct pair kernel, whatever the plan says
             if (conv_cfg_is_halo(cfg) && (!conv_halo_cfg_ok(a, cfg) || a.out_dt == DT_F32)) cfg = split_default_cfg(a);
             HIPCK(c, launch_conv_bf16(a, cfg, s));
         }
@@ -184,7 +188,7 @@ int run_layer(yolo_ctx *c, int i, int n)
         }
         break;
     case L_LOCAL: HIPCK(c, launch_local(nview(view_of(c, L.in[0])), nview(L.out), L.d_w, L.d_b, L.size, L.stride, L.pad, L.act, s)); break;
-    case L_UPSAMPLE: if (L.pair) { if (int r = via_f32(c, L, n, 0)) return r; break; } HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
+    case L_UPSAMPLE: if (L.pair) { if (getenv("YOLO_PAIR_UPSAMPLE_VIA_F32")) { if (int r = via_f32(c, L, n, 0)) return r; } else HIPCK(c, launch_upsample2x_pair(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break; } HIPCK(c, launch_upsample2x(nview(view_of(c, L.in[0])), nview(L.out), c->semantics == YOLO_SEM_TF, s)); break;
     case L_MAXPOOL: if (L.pair) { if (int r = via_f32(c, L, n, 1)) return r; break; } HIPCK(c, launch_maxpool(nview(view_of(c, L.in[0])), nview(L.out), L.psize, L.pstride, L.ppad, s)); break;
     case L_REORG: if (L.pair) { if (int r = via_f32(c, L, n, 2)) return r; break; } HIPCK(c, launch_reorg(nview(view_of(c, L.in[0])), nview(L.out), L.pstride, c->semantics == YOLO_SEM_DARKNET, s)); break;
     case L_DETECT: {
@@ -542,9 +546,10 @@ int yolo_autotune(yolo_ctx *c, int n, int iters)
     auto valid = [&](const Layer &L, int cfg) {
         if (fixed_kernel(L)) return false;                     // fused stem: nothing to choose
         ConvArgs a = conv_args(c, L, n);
+        if (a.split && conv_c8_direct_pair_ok(a)) return cfg == CONV_CFG_DIRECT;
+        if (cfg == CONV_CFG_DIRECT) return !a.split && conv_c8_direct_ok(a);
         if (a.pairk) return conv_cfg_pairk_ok(cfg, a.split != 0) && (!conv_cfg_is_halo(cfg) || (conv_halo_cfg_ok(a, cfg) && a.out_dt != DT_F32));
         if (a.split) return conv_cfg_split_ok(cfg) && (!conv_cfg_is_halo(cfg) || (conv_halo_cfg_ok(a, cfg) && a.out_dt != DT_F32));
-        if (cfg == CONV_CFG_DIRECT) return conv_c8_direct_ok(a);
         if (a.in_dt == DT_FP8) return conv_cfg_fp8_ok(cfg);
         return true;
     };
