@@ -263,10 +263,113 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     return YOLO_OK;
 }
 
+// ---- image windows over the first layers (round 6) -------------------------------------------------------------------------------
+// The first layers of a darknet move tensors far larger than the 256 MiB Infinity Cache at batch 32 (YOLOv3-416: 709 MB out of the
+// first conv as split-fp16 pairs, 177-354 MB per tensor down to the 104 x 104 stage; half of that in bf16) and run at their HBM floors:
+// a tensor is written to memory by one launch and read back from memory by the next.  Images are independent, so the same launches can
+// walk the batch in WINDOWS of `b` images -- layers 0..E on images [0, b), then on [b, 2b), ... -- with b chosen so that what a window's
+// layers touch fits the cache: a tensor is then still resident when its consumer reads it (8.6 TB/s against ~4-6 from HBM,
+// MI355X_MICROARCH.md 'Infinity Cache') and the pooled buffers are overwritten by the next window while resident.  Same kernels, same
+// per-image arithmetic (every tile walks K in the same order whatever the batch: tests/test_gpu_network.py batch independence), E * n / b
+// launches instead of E.  The window is applied by shifting the views the launch code reads (layer outputs, the network input, the
+// staged uint8 batch) and running the layers with n = b; nothing below run_layer knows about it.
+struct WindowPlan { int last = -1, b = 0; };            // layers 0..last run in windows of b images (last < 0: no windows)
+static WindowPlan window_plan(const yolo_ctx *c, int n)
+{
+    WindowPlan w;
+    // MEASURED (round 6, same-box A/B, tools/probe/ab_windows*.sh): it LOSES -- bf16 416 b32 13.55 -> 12.99 k img/s with windows of 8 images
+    // over the fused first layers, split-fp16 5.10 -> 4.90 k with windows of 4 over layers 0-11, and every (last, b) variant tried sits
+    // between: each extra launch costs its ~4-8 us and the consumer does not read faster.  OFF unless YOLO_WINDOWS asks for it ("auto", or
+    // "last,b" for a probe); the schedule stays as a knob for other topologies / batch sizes.
+    const char *e = getenv("YOLO_WINDOWS");
+    if (!e || c->keep_layers || c->dtype == YOLO_FP32 || n < 4) return w;
+    if (strcmp(e, "auto") != 0) {         // "last,b": probes
+        int l = -1, b = 0;
+        if (sscanf(e, "%d,%d", &l, &b) == 2 && l >= 0 && l < (int)c->layers.size() && b >= 1 && b < n) { w.last = l; w.b = b; }
+        return w;
+    }
+    const double cache = 256.0 * 1048576.0;
+    const int NL = (int)c->layers.size();
+    auto vbytes = [&](const TView &v) { return (double)v.h * v.w * v.stride * dt_size(v.dt); };
+    // per-image bytes each launch of the plain prefix (convs and the shortcuts folded into them) reads and writes in MATERIALISED tensors
+    int prefix = -1;
+    std::vector<double> need(NL, 0.0);
+    for (int i = 0; i < NL; ++i) {
+        const Layer &L = c->layers[i];
+        if (L.type == L_SHORTCUT && L.noop) { prefix = i; continue; }
+        if (L.type != L_CONV || L.fc || L.s2d7 || L.head || L.tail_on || L.fused_into >= 0) break;
+        double bytes = 0;
+        if (L.stem_skip || L.stem_tail || L.blk_skip) bytes = 0;                                   // computed inside a neighbour's launch
+        else if (L.stem) bytes = (double)c->in_h * c->in_w * 3 + vbytes(L.out) + (i + 1 < NL && c->layers[i + 1].stem_tail ? vbytes(c->layers[i + 1].out) : 0.0);
+        else if (L.blk) bytes = 2.0 * vbytes(view_of(c, c->layers[i - 1].in[0])) + vbytes(L.out) - vbytes(view_of(c, c->layers[i - 1].in[0]));      // x in (shortcut from L2), y out
+        else {
+            bytes = vbytes(view_of(c, L.in[0])) + vbytes(L.out);
+            if (L.residual_from >= -1) bytes += vbytes(view_of(c, L.residual_from));
+        }
+        need[i] = bytes; prefix = i;
+    }
+    // ... as far as a launch's whole-batch traffic exceeds most of the cache (beyond that point tensors already live in it)
+    int last = -1;
+    for (int i = 0; i <= prefix; ++i) if (need[i] * n > 0.7 * cache) last = i;
+    if (last < 0) return w;
+    double biggest = 0;
+    for (int i = 0; i <= last; ++i) biggest = std::max(biggest, need[i]);
+    int b = n;
+    while (b > 1 && biggest * b > 0.55 * cache) b = (b + 1) / 2;
+    if (b >= n || b < 2) return w;
+    // a window must still fill the chip: the tiled layers need about one tile per CU (the fused first-layer kernels are persistent)
+    for (int i = 0; i <= last; ++i) {
+        const Layer &L = c->layers[i];
+        if (L.type != L_CONV || fixed_kernel(L) || need[i] == 0) continue;
+        const double tiles = std::ceil((double)b * L.H * L.W / 176.0) * std::ceil(L.filters / 128.0);
+        if (tiles < 224) { last = i - 1; break; }
+    }
+    while (last >= 0 && (c->layers[last].blk_skip || c->layers[last].stem_skip)) --last;          // never split a fused group
+    while (last + 1 <= prefix && ((c->layers[last + 1].type == L_SHORTCUT && c->layers[last + 1].noop) || c->layers[last + 1].stem_tail)) ++last;
+    if (last < 0) return w;
+    w.last = last; w.b = b;
+    return w;
+}
+// shift every view layers 0..last (and the input) by `img` images (sign: +1 apply, -1 undo)
+static void window_shift(yolo_ctx *c, int last, long img)
+{
+    auto adv = [&](TView &v) { if (v.ptr) v.ptr = (char *)v.ptr + img * (long)v.h * v.w * v.stride * (long)dt_size(v.dt); };
+    adv(c->input);
+    for (int i = 0; i <= last; ++i) adv(c->layers[i].out);
+    if (c->stem_u8) c->stem_u8 += img * (long)c->in_h * c->in_w * 3;
+}
+// the layer sequence of one forward: windows over the first layers, then the rest on the whole batch.  `skip_conv`: the timing pass that
+// runs everything but the convs; `ev` / `acc_ms`: per-layer events (yolo_time_layers)
+static int run_layers(yolo_ctx *c, int n, bool skip_conv = false, std::vector<hipEvent_t> *ev = nullptr)
+{
+    const int NL = (int)c->layers.size();
+    const WindowPlan w = window_plan(c, n);
+    int first_whole = 0;
+    if (w.last >= 0 && !ev) {
+        for (int img = 0; img < n; img += w.b) {
+            const int nb = std::min(w.b, n - img);
+            window_shift(c, w.last, img);
+            int r = YOLO_OK;
+            for (int i = 0; i <= w.last && r == YOLO_OK; ++i) {
+                if (skip_conv && c->layers[i].type == L_CONV) continue;
+                r = run_layer(c, i, nb);
+            }
+            window_shift(c, w.last, -img);
+            if (r) return r;
+        }
+        first_whole = w.last + 1;
+    }
+    for (int i = first_whole; i < NL; ++i) {
+        if (!(skip_conv && c->layers[i].type == L_CONV)) { int r = run_layer(c, i, n); if (r) return r; }
+        if (ev) HIPCK(c, hipEventRecord((*ev)[i + 1], c->stream));
+    }
+    return YOLO_OK;
+}
+
 int run_network(yolo_ctx *c, int n, bool lean)
 {
     c->lean = lean && c->lean_ok;
-    for (int i = 0; i < (int)c->layers.size(); ++i) { int r = run_layer(c, i, n); if (r) { c->lean = false; return r; } }
+    { int r = run_layers(c, n); if (r) { c->lean = false; return r; } }
     c->last_n = n; c->scores_mode = 0; c->det_valid = !c->lean;
     return YOLO_OK;
 }
@@ -488,11 +591,7 @@ int yolo_time_forward(yolo_ctx *c, int n, int iters, float *total_ms, float *con
         float all_ms = 0, rest_ms = 0;
         for (int pass = 0; pass < 2; ++pass) {
             HIPCK(c, hipEventRecord(e0, c->stream));
-            for (int it = 0; it < iters; ++it)
-                for (int i = 0; i < (int)c->layers.size(); ++i) {
-                    if (pass == 1 && c->layers[i].type == L_CONV) continue;
-                    int r = run_layer(c, i, n); if (r) return r;
-                }
+            for (int it = 0; it < iters; ++it) { int r = run_layers(c, n, pass == 1); if (r) return r; }        // (the forward's own schedule, image windows included)
             HIPCK(c, hipEventRecord(e1, c->stream)); HIPCK(c, hipEventSynchronize(e1));
             float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); (pass == 0 ? all_ms : rest_ms) = ms / iters;
         }
