@@ -1,0 +1,231 @@
+// Fused first two convs of a darknet in the split-fp16 configuration (YOLO_FP16X2; round 6): conv0 (3x3 / stride 1, image -> C0 <= 32
+// channels) and conv1 (3x3 / stride 2, 32 -> 64 channels) in ONE launch, conv0's tensor never materialised.  As separate launches they are
+// the two largest memory movers of the network -- conv0 writes 709 MB of pairs at 416 x 416 x 32 that conv1 reads straight back (270 +
+// 264 us, both at their traffic floors) -- exactly what the bf16 configuration's conv_stem_c32_c64 removes for 16-bit storage
+// (conv_stem.hip; the reference's darknet-53 layers 0-1, V3/yolo_v3.py:22-24, DN cfg layers 0-1).
+//
+// One persistent 8-wave workgroup per CU walks 8 x 16 tiles of conv1 pixels.  Per tile:
+//   A  the 19 x 35 image pixels the tile needs (three 16-byte pieces each: hi | lo | hi of the 8 padded channels, PAIR_B3) come into LDS --
+//      fetched into registers during the previous tile's phase C, written after it; out-of-image pixels are zeros (conv0's padding);
+//   B  conv0 on the 17 x 33 pixels conv1 reads: 36 groups of 16 pixels over the 8 waves, per group the direct kernel's arithmetic
+//      (conv_c8_3x3_direct_pair: per K-group W_hi x_hi, W_lo x_hi, W_hi x_lo; bias, leaky, split) -> an LDS tile of interleaved pairs
+//      (64 B hi | 64 B lo per pixel, pitch 144 B); pixels outside the image are conv1's zero padding: zeros;
+//   C  conv1 from that tile: wave (cg, pq) owns 32 output channels (filters W1_hi / W1_lo register-resident, 144 VGPRs) x 2 output rows;
+//      per tap and sub-tile the pair K loop's three products in its order (A, B, C per accumulator and K-step, taps ascending);
+//   E  bias, leaky, split; each wave's 16 pixels x (32 hi | 32 lo) leave through a private LDS slab as whole 128-byte rows (sc1).
+// Every intermediate keeps the rounding points and the K order of the separate launches (the direct first-layer kernel and the tiled pair
+// kernel): the fused plan is bit-identical to the layer-by-layer plan (tests/test_gpu_fp16x2.py).
+#include "conv_igemm_kernel.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int SP_TH = 8, SP_TW = 16;                       // conv1 pixels per tile
+constexpr int SP_IH = 2 * SP_TH + 3, SP_IW = 2 * SP_TW + 3; // 19 x 35 image pixels
+constexpr int SP_MH = 2 * SP_TH + 1, SP_MW = 2 * SP_TW + 1; // 17 x 33 conv0 pixels
+constexpr int SP_IPIX = 48;                                // bytes of an image pixel record (hi 8 | lo 8 | hi 8)
+constexpr int SP_MPIX = 144;                               // pitch of a conv0 pixel in LDS (64 B hi | 64 B lo | 16 B pad)
+constexpr int SP_IBYTES = SP_IH * SP_IW * SP_IPIX;          // 31 920
+constexpr int SP_MBYTES = SP_MH * SP_MW * SP_MPIX;          // 80 784
+constexpr int SP_SLAB = 16 * 144;                          // one wave's output slab
+constexpr int SP_NPIECE = SP_IH * SP_IW * 3;               // 16-byte pieces of an image tile: 1995
+constexpr int SP_PPT = (SP_NPIECE + 511) / 512;            // per thread: 4
+constexpr int SP_W0 = 12 * 1024;                            // conv0's filter fragments (W_hi / W_lo x 2 channel tiles x 3 K-groups), one KiB each, in LDS
+constexpr int SP_LDS = ((SP_IBYTES + 15) / 16 * 16) + SP_MBYTES + 8 * SP_SLAB + SP_W0;
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv_stem_pair_c32_c64(const StemPairArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    fp16_saturating_mode();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const I0 = smem;                                          // image tile
+    char *const M0 = smem + (SP_IBYTES + 15) / 16 * 16;             // conv0 tile (pairs)
+    char *const slab = M0 + SP_MBYTES + (threadIdx.x >> 6) * SP_SLAB;
+    char *const W0S = M0 + SP_MBYTES + 8 * SP_SLAB;                  // fragment f = (i * 3 + kk) * 2 + (0 hi | 1 lo): lane's 16 bytes at f * 1024 + lane * 16
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 1, pq = wave >> 1;                        // phase C: channel half (32 channels), output rows 2 pq, 2 pq + 1
+    const int tx_n = (a.Wo + SP_TW - 1) / SP_TW, ty_n = (a.Ho + SP_TH - 1) / SP_TH;
+    const int tiles = a.N * ty_n * tx_n;
+    const bf16_t *__restrict__ in = (const bf16_t *)a.in;
+
+    // conv1 filters of this wave's 32 channels, register-resident: A fragment (i, tap): row cg * 32 + i * 16 + l15, elements tap * 64 + lq * 8 (hi), + 32 (lo)
+    bf16x8 w1h[2][9], w1l[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bf16_t *row = (const bf16_t *)a.w1 + (size_t)(cg * 32 + i * 16 + l15) * a.Kpad1 + t * 64 + lq * 8;
+            w1h[i][t] = *(const bf16x8 *)row; w1l[i][t] = *(const bf16x8 *)(row + 32);
+        }
+    const float slope0 = a.act0 == ACT_LEAKY ? 0.1f : 1.0f, slope1 = a.act1 == ACT_LEAKY ? 0.1f : 1.0f;
+
+    auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
+        n = tile / (ty_n * tx_n); const int r = tile - n * ty_n * tx_n; const int ty = r / tx_n;
+        oy0 = ty * SP_TH; ox0 = (r - ty * tx_n) * SP_TW;
+    };
+    // phase A, first half: this thread's pieces of tile `tile`'s image window into registers (zeros outside the image)
+    uint4 pre[SP_PPT];
+    auto fetch = [&](int tile) {
+        int n, oy0, ox0; tile_origin(tile, n, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < SP_PPT; ++k) {
+            const int pc = tid + k * 512;
+            const int px = pc / 3, part = pc - px * 3, r = px / SP_IW, c = px - r * SP_IW;
+            const int y = 2 * oy0 - 2 + r, x = 2 * ox0 - 2 + c;
+            const bool ok = pc < SP_NPIECE && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            pre[k] = ok ? *(const uint4 *)(in + ((size_t)(n * a.H + y) * a.W + x) * 24 + part * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < SP_PPT; ++k) { const int pc = tid + k * 512; if (pc < SP_NPIECE) *(uint4 *)(I0 + pc * 16) = pre[k]; }
+    };
+
+    // conv0's filters (32 x 216, pairs): too many registers beside conv1's 144 -- kept in LDS in fragment order, re-read per 16-pixel group
+    for (int f = wave; f < 12; f += 8) {
+        const int i = f / 6, kk = (f >> 1) % 3, lo = f & 1, tap = kk * 4 + lq;
+        const bf16_t *row = (const bf16_t *)a.w0 + (size_t)(i * 16 + l15) * a.Kpad0 + tap * 24 + lo * 16;
+        *(uint4 *)(W0S + f * 1024 + lane * 16) = tap < 9 ? *(const uint4 *)row : uint4{0u, 0u, 0u, 0u};
+    }
+    int tile = blockIdx.x;
+    if (tile < tiles) { fetch(tile); stash(); }
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+        int n, oy0, ox0; tile_origin(tile, n, oy0, ox0);
+        // ---- phase B: conv0 on the 17 x 33 pixels, 16 at a time ----
+        {
+            f32x4 b0v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b0v[i] = *(const f32x4 *)(a.b0 + i * 16 + lq * 4);
+            constexpr int NG = (SP_MH * SP_MW + 15) / 16;          // 36 groups
+            // (Tried and dropped: K-group outermost with the wave's five groups' accumulators live, so that a filter fragment is read from
+            // LDS once per tile instead of once per group -- 58 spilled registers beside conv1's 144, 482 -> 760 us.)
+            for (int g = wave; g < NG; g += 8) {
+                const int q = g * 16 + l15;
+                const bool qv = q < SP_MH * SP_MW;
+                const int qq = qv ? q : 0, my = qq / SP_MW, mx = qq - my * SP_MW;
+                bf16x8 xh[3], xl[3];
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int tap = kk * 4 + lq;
+                    const int kh = (tap * 11) >> 5, kw = tap - kh * 3;
+                    if (tap < 9) {
+                        const char *p = I0 + ((my + kh) * SP_IW + mx + kw) * SP_IPIX;
+                        xh[kk] = *(const bf16x8 *)p; xl[kk] = *(const bf16x8 *)(p + 16);
+                    } else { xh[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xl[kk] = xh[kk]; }
+                }
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    bf16x8 wh[2], wl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { wh[i] = *(const bf16x8 *)(W0S + ((i * 3 + kk) * 2) * 1024 + lane * 16); wl[i] = *(const bf16x8 *)(W0S + ((i * 3 + kk) * 2 + 1) * 1024 + lane * 16); }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mma16<true>(wh[i], xh[kk], acc[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mma16<true>(wl[i], xh[kk], acc[i]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mma16<true>(wh[i], xl[kk], acc[i]);
+                }
+                // conv0 pixel (y, x) of the image; outside it: conv1's zero padding
+                const int y = 2 * oy0 - 1 + my, x = 2 * ox0 - 1 + mx;
+                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                if (qv) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float v[4] = {acc[i][0] + b0v[i][0], acc[i][1] + b0v[i][1], acc[i][2] + b0v[i][2], acc[i][3] + b0v[i][3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = vmax_f32(v[e], v[e] * slope0); v[e] = inside && (i * 16 + lq * 4 + e) < a.C0 ? v[e] : 0.f; }
+                        uint2 H, L;
+                        H.x = pack16x2<true>(v[0], v[1]); H.y = pack16x2<true>(v[2], v[3]);
+                        L.x = pack16x2<true>(v[0] - unpack16_lo<true>(H.x), v[1] - unpack16_hi<true>(H.x));
+                        L.y = pack16x2<true>(v[2] - unpack16_lo<true>(H.y), v[3] - unpack16_hi<true>(H.y));
+                        *(uint2 *)(M0 + q * SP_MPIX + i * 32 + lq * 8) = H;
+                        *(uint2 *)(M0 + q * SP_MPIX + 64 + i * 32 + lq * 8) = L;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // conv0 tile complete; the image tile is no longer read
+        const int next = tile + gridDim.x;
+        if (next < tiles) fetch(next);                     // phase A of the next tile rides under phase C
+        // ---- phase C: conv1, this wave's 32 channels x 2 output rows ----
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - kh * 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = 2 * pq + j;
+                const char *p = M0 + ((2 * oy + kh) * SP_MW + 2 * l15 + kw) * SP_MPIX + lq * 16;
+                const bf16x8 xh = *(const bf16x8 *)p, xl = *(const bf16x8 *)(p + 64);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mma16<true>(w1h[i][t], xh, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mma16<true>(w1l[i][t], xh, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mma16<true>(w1h[i][t], xl, acc[i][j]);
+            }
+        }
+        // ---- epilogue: bias, leaky, split; 16 pixels x (32 hi | 32 lo) per sub-tile through the wave's slab as whole 128-byte rows ----
+        f32x4 b1v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b1v[i] = *(const f32x4 *)(a.b1 + cg * 32 + i * 16 + lq * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = oy0 + 2 * pq + j;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[4] = {acc[i][j][0] + b1v[i][0], acc[i][j][1] + b1v[i][1], acc[i][j][2] + b1v[i][2], acc[i][j][3] + b1v[i][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = vmax_f32(v[e], v[e] * slope1);
+                uint2 H, L;
+                H.x = pack16x2<true>(v[0], v[1]); H.y = pack16x2<true>(v[2], v[3]);
+                L.x = pack16x2<true>(v[0] - unpack16_lo<true>(H.x), v[1] - unpack16_hi<true>(H.x));
+                L.y = pack16x2<true>(v[2] - unpack16_lo<true>(H.y), v[3] - unpack16_hi<true>(H.y));
+                *(uint2 *)(slab + l15 * 144 + i * 32 + lq * 8) = H;
+                *(uint2 *)(slab + l15 * 144 + 64 + i * 32 + lq * 8) = L;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (oy < a.Ho) {
+                const char *obase = (const char *)a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox0) * a.out_stride * 2 + cg * 128;      // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int pc = lane + 64 * k, px = pc >> 3, c16 = pc & 7;
+                    const uint4 o = *(const uint4 *)(slab + px * 144 + c16 * 16);
+                    if (ox0 + px < a.Wo) out_store16_at(obase, (unsigned)(px * a.out_stride * 2 + c16 * 16), o.x, o.y, o.z, o.w);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slab is rewritten by the next sub-tile
+        }
+        if (next < tiles) stash();                         // (the image tile was free since the barrier above)
+        __syncthreads();                                   // next image tile in LDS; the conv0 tile is free again
+    }
+#endif
+}
+
+bool conv_stem_pair_ok(const StemPairArgs &a)
+{
+    return a.in && a.w0 && a.w1 && a.out && (a.C0 == 16 || a.C0 == 32) && a.Kpad0 >= 216 && a.Kpad1 == 576 && a.out_stride >= 128 && a.H % 2 == 0 && a.W % 2 == 0 &&
+           a.Ho == a.H / 2 && a.Wo == a.W / 2 && !getenv("YOLO_NO_PAIR_STEM");
+}
+
+hipError_t launch_conv_stem_pair(const StemPairArgs &a, hipStream_t s)
+{
+    if (!conv_stem_pair_ok(a)) return hipErrorInvalidValue;
+    hipError_t e = conv_opt_in_lds((const void *)conv_stem_pair_c32_c64, SP_LDS);
+    if (e != hipSuccess) return e;
+    static int cus = 0;             // (one device model per process: MI355X)
+    if (!cus) { int dev = 0; hipDeviceProp_t p; cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }
+    const long tiles = (long)a.N * ((a.Ho + SP_TH - 1) / SP_TH) * ((a.Wo + SP_TW - 1) / SP_TW);
+    const long grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL(conv_stem_pair_c32_c64, dim3((unsigned)grid), dim3(512), SP_LDS, s, a);
+    return hipGetLastError();
+}

@@ -143,6 +143,16 @@ bool conv_cfg_split_ok(int cfg);      // tile configurations instantiated for sp
 bool conv_cfg_pairk_ok(int cfg, bool split_out);      // ... and for a conv that READS interleaved pairs (pair K loop), writing pairs / plain fp16 or an fp32 head
 hipError_t launch_conv_pair(const ConvArgs &a, int cfg, hipStream_t s);
 // first layer of a split-fp16 network (image in three blocks hi | lo | hi -> interleaved pairs): the direct kernel, no LDS (conv_pair.hip)
+// fused conv0 + conv1 of a split-fp16 network (conv_stem_pair.hip): image in three blocks -> conv1's interleaved pairs, conv0 never materialised
+struct StemPairArgs {
+    const void *in;                 // [N, H, W, 24] f16: hi | lo | hi blocks of the 8 padded channels
+    const void *w0; const float *b0; int Kpad0, C0, act0;      // conv0: rows [tap][hi 8 | hi 8 | lo 8] (k = tap * 24 + ...), C0 = 16 or 32 filters
+    const void *w1; const float *b1; int Kpad1, act1;          // conv1: rows [tap][W_hi 32 | W_lo 32] (k = tap * 64 + ...), 64 filters
+    void *out; int out_stride;      // [N, Ho, Wo, >= 128] f16 interleaved pairs (two 32-channel groups)
+    int N, H, W, Ho, Wo;
+};
+bool conv_stem_pair_ok(const StemPairArgs &a);
+hipError_t launch_conv_stem_pair(const StemPairArgs &a, hipStream_t s);
 bool conv_c8_direct_pair_ok(const ConvArgs &a);
 hipError_t launch_conv_c8_direct_pair(const ConvArgs &a, hipStream_t s);      // the tiled pair-K-loop instantiations (conv_pair.hip); the halo ones: launch_conv_halo13
 hipError_t launch_conv_fp8(const ConvArgs &a, int cfg, hipStream_t s);

@@ -75,7 +75,7 @@ double yolo_conv_bytes(const yolo_ctx *c, int n)
         TView in = view_of(c, L.in[0]);
         const double ie = (double)dt_size(L.in_dt), oe = (double)dt_size(L.out.dt);
         if (!L.stem && !L.stem_tail && !L.blk) b += (double)n * in.h * in.w * L.cin * ie;         // the fused stem / residual block keep these inputs in LDS
-        if (!L.stem_skip && !L.blk_skip) b += (double)n * L.H * L.W * L.filters * oe;
+        if (!L.stem_skip && !L.blk_skip && !L.pstem_skip) b += (double)n * L.H * L.W * L.filters * oe;
         b += (double)L.filters * L.cin * L.size * L.size * ie;
     }
     return b;

@@ -40,6 +40,7 @@ struct Layer {
     bool head = false;                   // conv feeding a yolo/region layer: fp32 output
     float *d_obj = nullptr;              // ... feeding a [yolo] layer (bf16 / fp8 networks): compact plane of its objectness logits [max_batch * H * W][anchors]
     bool stem_skip = false, stem = false;   // fused stem (conv_stem.hip): layer 0 is never materialised, layer 1 launches both
+    bool pstem_skip = false, pstem = false; // ... the same fusion in a split-fp16 network (conv_stem_pair.hip): image pairs -> conv1's pairs in one launch
     bool blk_skip = false, blk = false;     // fused residual block (conv_block.hip): this 1x1 conv is computed inside the launch of the 3x3 conv that follows / this 3x3 conv launches both
     bool stem_tail = false;                 // ... and this 1x1 conv (layer 2) is computed by that launch too
     bool halo = false;                      // 3x3/s1, 32 -> 64 channels: halo-staged kernel instead of the tiled one

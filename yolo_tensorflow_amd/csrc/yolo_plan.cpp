@@ -260,6 +260,15 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
             }
         }
     }
+    // split-fp16: conv0 + conv1 on pairs in one launch (conv_stem_pair.hip) -- both tensors pairs, the image in its three blocks
+    if (c->split() && !c->keep_layers && NL >= 2 && c->in_pair && !getenv("YOLO_NO_PAIR_STEM")) {
+        const Layer &A = c->layers[0], &B = c->layers[1];
+        if (A.type == L_CONV && B.type == L_CONV && uses[0] == 1 && B.in[0] == 0 && A.size == 3 && A.stride == 1 && A.pad == 1 && A.cin == 3 && A.bn == B.bn &&
+            (A.filters == 32) && B.size == 3 && B.stride == 2 && B.pad == 1 && B.filters == 64 && !A.head && !B.head && A.residual_from < -1 && B.residual_from < -1 &&
+            A.pair && B.pair && c->in_h % 2 == 0 && c->in_w % 2 == 0 && A.kpad >= 216 && B.kpad == 576) {
+            c->layers[0].pstem_skip = true; c->layers[1].pstem = true;
+        }
+    }
     if (ctx16 && !getenv("YOLO_NO_HALO"))
         for (int i = 1; i < NL; ++i) {
             Layer &L = c->layers[i];
@@ -327,7 +336,7 @@ int build_plan(yolo_ctx *c, const std::vector<Section> &secs)
         if (L.type == L_YOLO || L.type == L_REGION || L.type == L_DETECT) { L.noop = true; L.storage = c->layers[i - 1].storage; L.ch_off = c->layers[i - 1].ch_off; continue; }
         if (L.type == L_ROUTE && L.in.size() == 1) { L.noop = true; int j = L.in[0]; if (j < 0) return fail(c, YOLO_ERR_UNSUPPORTED, "route to network input"); L.storage = c->layers[j].storage; L.ch_off = c->layers[j].ch_off; continue; }
         if (L.type == L_ROUTE) continue;
-        if (L.stem_skip) { L.noop = true; continue; }               // lives in LDS only
+        if (L.stem_skip || L.pstem_skip) { L.noop = true; continue; }               // lives in LDS only
         if (place_route[i] >= 0) { L.storage = c->layers[place_route[i]].storage; L.ch_off = place_off[i]; }
         else if (L.head) L.storage = new_storage(roundup(L.C, 4), DT_F32, (size_t)c->max_batch * L.H * L.W, true);
         else L.storage = new_storage(L.pair ? pair_width(L.C) : roundup(L.C, gran_of(L.store_dt)), L.store_dt, (size_t)c->max_batch * L.H * L.W, c->keep_layers);
@@ -462,7 +471,7 @@ int allocate(yolo_ctx *c)
     if (c->dtype != YOLO_FP32)
         for (size_t i = 0; i < c->layers.size(); ++i) {
             const Layer &L = c->layers[i];
-            if (L.type != L_CONV || L.fc || L.s2d7 || L.stem_skip || L.stem || L.stem_tail || L.blk_skip) continue;     // (fused layers: their launch checks its own windows)
+            if (L.type != L_CONV || L.fc || L.s2d7 || L.stem_skip || L.stem || L.stem_tail || L.blk_skip || L.pstem_skip || L.pstem) continue;     // (fused layers: their launch checks its own windows)
             const TView in = view_of(c, L.in[0]);
             const double per_image = (double)in.h * in.w * in.stride * dt_size(L.in_dt), slack = 2.0 * (in.w + 1) * in.stride * dt_size(L.in_dt);
             if (per_image * c->max_batch + slack >= 2147483648.0)
@@ -472,6 +481,6 @@ int allocate(yolo_ctx *c)
     return YOLO_OK;
 }
 
-bool fixed_kernel(const Layer &L) { return L.stem || L.stem_skip || L.stem_tail || L.halo || L.s2 || L.blk || L.blk_skip; }
+bool fixed_kernel(const Layer &L) { return L.stem || L.stem_skip || L.stem_tail || L.halo || L.s2 || L.blk || L.blk_skip || L.pstem || L.pstem_skip; }
 
 }  // namespace yolo_impl

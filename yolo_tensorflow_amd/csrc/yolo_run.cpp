@@ -94,7 +94,17 @@ int run_layer(yolo_ctx *c, int i, int n)
     auto nview = [&](TView v) { v.n = n; return v; };
     switch (L.type) {
     case L_CONV: {
-        if (L.stem_skip || L.stem_tail) break;
+        if (L.stem_skip || L.stem_tail || L.pstem_skip) break;
+        if (L.pstem) {           // split-fp16: conv0 + conv1 in one launch (conv_stem_pair.hip)
+            const Layer &A = c->layers[0];
+            StemPairArgs t; memset(&t, 0, sizeof t);
+            t.in = c->input.ptr; t.w0 = A.d_w; t.b0 = A.d_b; t.Kpad0 = A.kpad; t.C0 = A.filters; t.act0 = A.act;
+            t.w1 = L.d_w; t.b1 = L.d_b; t.Kpad1 = L.kpad; t.act1 = L.act;
+            t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W;
+            if (c->input.stride != 24 || !conv_stem_pair_ok(t)) return fail(c, YOLO_ERR_STATE, "layer %d: the fused split-fp16 stem does not apply to this plan", i);
+            HIPCK(c, launch_conv_stem_pair(t, s));
+            break;
+        }
         if (L.fused_into >= 0 && c->layers[L.fused_into].tail_on) break;        // computed in the producer's epilogue
         if (L.stem) {
             const Layer &A = c->layers[0];
@@ -299,7 +309,7 @@ static WindowPlan window_plan(const yolo_ctx *c, int n)
         if (L.type == L_SHORTCUT && L.noop) { prefix = i; continue; }
         if (L.type != L_CONV || L.fc || L.s2d7 || L.head || L.tail_on || L.fused_into >= 0) break;
         double bytes = 0;
-        if (L.stem_skip || L.stem_tail || L.blk_skip) bytes = 0;                                   // computed inside a neighbour's launch
+        if (L.stem_skip || L.stem_tail || L.blk_skip || L.pstem_skip) bytes = 0;                                   // computed inside a neighbour's launch
         else if (L.stem) bytes = (double)c->in_h * c->in_w * 3 + vbytes(L.out) + (i + 1 < NL && c->layers[i + 1].stem_tail ? vbytes(c->layers[i + 1].out) : 0.0);
         else if (L.blk) bytes = 2.0 * vbytes(view_of(c, c->layers[i - 1].in[0])) + vbytes(L.out) - vbytes(view_of(c, c->layers[i - 1].in[0]));      // x in (shortcut from L2), y out
         else {
