@@ -143,6 +143,9 @@ def tolerance_line(hip, IO, base_cfg_txt, flat, args, dev, stream, images, refs,
                             "kernel_ms_per_forward": round(conv_ms, 4), "forward_ms": round(total_ms, 4),
                             "note": "achieved / frac count the ALGORITHMIC FLOPs (the reference's formula); mfma_* the products the matrix pipe executes"},
                "tolerance": "north_star: decoded boxes within IoU >= 0.999 of the fp32 reference on identical inputs"}
+        if not args.no_calibration:      # the fp16 MFMA's own yardstick on this box (the pair K loop runs v_mfma_f32_16x16x32_f16)
+            ct, cg = hip.calibrate(0.3, f16=True, device=dev.index, stream=stream.cuda_stream)
+            out["roofline"].update({"calib_tflops": round(ct, 1), "clock_ghz": round(cg, 3), "mfma_frac_of_calib": round(achieved * products / ct, 4) if ct > 0 else None})
         if refs is not None:
             out["parity"] = parity(eng, refs, imgs_par)
         return out

@@ -1,6 +1,6 @@
 """Split-fp16 configuration (YOLO_FP16X2, round 4): every filter and stored activation is a pair of fp16 numbers hi = f16(v),
 lo = f16(v - hi); a conv forms W_hi x_hi + W_hi x_lo + W_lo x_hi on the fp16 MFMA with fp32 accumulation.  It exists because no 16-bit
-STORAGE type reaches north_star's IoU >= 0.999 on weights with a trained file's batch-norm statistics (tools/study_bits.py: 17 significand
+STORAGE type reaches north_star's IoU >= 0.999 on weights with a trained file's batch-norm statistics (tools/study/study_bits.py: 17 significand
 bits are needed there; bf16 has 8, fp16 11); this configuration carries 22.
 
 Checked here, all through the C ABI: the conv operator against the oracle's restatement of the scheme (oracle.forward_f16x2 pieces) on the
@@ -306,7 +306,7 @@ def test_mixed16_refuses_mismatched_operands(hiplib):
 def test_mixed16_first_layers_plan_on_natural_images(hiplib, stats):
     """The committed mixed plan (pairs on the image and cfg layers 0..11, plain fp16 after them: tuned/yolov3_416_b32_mixed16.json) on the
     reference's six jpgs against the fp32 oracle, next to what plain fp16 and pairs everywhere give there (tests above, test_gpu_fp16.py):
-    rounding noise injected EARLY is what the stack multiplies (tools/study_mixed16.py), so pairs on the first 16 % of the FLOPs buy most
+    rounding noise injected EARLY is what the stack multiplies (tools/study/study_mixed16.py), so pairs on the first 16 % of the FLOPs buy most
     of what pairs everywhere buy."""
     import json
     from test_gpu_natural import _weights, _oracle, IMAGES, _load, real_split

@@ -148,7 +148,7 @@ def test_reference_images_through_the_detector(hiplib, stats, dtype_name):
         assert lost == 0 and miou >= BF16_IOU and mds <= 1e-2
     elif dtype_name == "bf16":
         # trained-file statistics: bf16's 8-bit significand costs far more than on benign statistics -- the oracle's own bf16-storage
-        # emulation shows the same loss (tools/study_bits.py: min IoU 0.76 on the drawn `log` vectors, 0.976 on the `real` ones).  What is
+        # emulation shows the same loss (tools/study/study_bits.py: min IoU 0.76 on the drawn `log` vectors, 0.976 on the `real` ones).  What is
         # asserted is that the device IS that emulation (same roundings, different fp32 summation order), and a floor just under the
         # measured deviation from the fp32 oracle.
         osecs = R.parse_cfg(txt); params = R.unflatten_weights(flat, osecs)

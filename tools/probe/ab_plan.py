@@ -1,11 +1,11 @@
 """Same-box A/B of tile plans (boxes differ by several per cent, so plans are only ever compared inside one process):
 interleaved rounds of yolo_time_forward for each plan, median conv / forward ms per plan.
 
-  python tools/ab_plan.py tools/probe/plan_r01_416_b32_bf16.json yolo_tensorflow_amd/tuned/yolov3_416_b32_bf16.json
+  python tools/probe/ab_plan.py tools/probe/plan_r01_416_b32_bf16.json yolo_tensorflow_amd/tuned/yolov3_416_b32_bf16.json
 """
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 
 B = int(os.environ.get("B", "32")); size = int(os.environ.get("SIZE", "416")); DT = os.environ.get("DTYPE", "bf16"); R = int(os.environ.get("ROUNDS", "7"))

@@ -1,4 +1,4 @@
-"""Aggregates tools/layer_table.py output (stdin) by layer class: us per class."""
+"""Aggregates tools/probe/layer_table.py output (stdin) by layer class: us per class."""
 import re, sys, collections
 cls = collections.OrderedDict(); last = ""
 for l in sys.stdin:

@@ -2,7 +2,7 @@
 (YOLO_CONV_DIAG=1: tiled p176c128_s2; YOLO_CONV_DIAG=free: free-running halo form f176c256)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip
 rng = np.random.default_rng(0)
 for mode in os.environ.get("MODES", "1,free").split(","):

@@ -1,7 +1,7 @@
 """Developer check of the fp8 configuration on the GPU: conv operator and a small network against the oracle's emulation."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 from oracle import yolo_ref as R
 

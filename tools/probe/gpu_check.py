@@ -1,7 +1,7 @@
 """Developer smoke run on a GPU box: a few operators + a small network against the oracle, then timing."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import hip, darknet_io as IO
 

@@ -3,7 +3,7 @@ The slope is the cost of a K-step (64 input channels of one tap), the intercept 
 epilogue, store drain).  A throw-away topology built here; per-layer HIP events (each adds ~5 us, the no-op layers show it)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 
 B = int(os.environ.get("B", "32"))

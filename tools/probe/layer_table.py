@@ -1,19 +1,19 @@
 """Per-layer device time of the tuned YOLOv3-416 batch-32 plan: layer, kind, shape, tile cfg, ms, TFLOP/s."""
 import sys, os, json
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 B = int(os.environ.get("B", "32")); size = int(os.environ.get("SIZE", "416")); DT = os.environ.get("DTYPE", "bf16")
 txt = IO.with_input_size(IO.cfg_text("yolov3"), size); secs = IO.parse_cfg(txt)
 eng = hip.Engine(txt, max_batch=B, dtype={"bf16": hip.BF16, "fp8": hip.FP8}[DT]); eng.set_weights(IO.synth_weights(secs, 0))
 img = np.random.default_rng(0).integers(0, 256, (B, size, size, 3), dtype=np.uint8)
 eng.forward(img, want_detections=False)
-plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (size, B, DT))
+plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "yolo_tensorflow_amd", "tuned", "yolov3_%d_b%d_%s.json" % (size, B, DT))
 if os.path.exists(plan) and os.environ.get("TUNE", "0") != "1":
     eng.set_tile_configs(json.load(open(plan))["cfgs"])
 else:
     eng.autotune(B, int(os.environ.get("TUNE_ITERS", "3")))
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out"); os.makedirs(out, exist_ok=True)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out"); os.makedirs(out, exist_ok=True)
     json.dump({"num_cfgs": hip.op_conv_num_cfgs(), "cfgs": [int(v) for v in eng.get_tile_configs()]}, open(os.path.join(out, "yolov3_%d_b%d_%s.json" % (size, B, DT)), "w"))
 cfgs = eng.get_tile_configs()
 ms = eng.time_layers(B, 20)

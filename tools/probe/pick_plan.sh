@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box plan selection: tune several candidate tile plans (the in-situ tuner's near-ties fall differently from run to
-# run), measure each one twice with the plan fixed, keep the fastest.   usage: tools/pick_plan.sh [bf16|fp8] [candidates]
+# run), measure each one twice with the plan fixed, keep the fastest.   usage: tools/probe/pick_plan.sh [bf16|fp8] [candidates]
 DT=${1:-bf16}; N=${2:-3}
 PLAN=yolo_tensorflow_amd/tuned/yolov3_416_b32_$DT.json
 cp $PLAN gpurun_out/plan_0.json

@@ -3,7 +3,7 @@ detections on every one of many repeated forwards, eager and graph-replayed, bf1
 passes through one LDS tile)."""
 import sys, os, json
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 N = int(os.environ.get("REPS", "300")); B = 32
 txt = IO.cfg_text("yolov3"); secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 0)
@@ -12,7 +12,7 @@ dimg = torch.from_numpy(img).cuda()
 for name, dt in (("bf16", hip.BF16), ("fp8", hip.FP8), ("fp16x2", hip.FP16X2)):
     eng = hip.Engine(txt, max_batch=B, dtype=dt)
     eng.set_weights(flat)
-    plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_%s.json" % name)
+    plan = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_%s.json" % name)
     eng.set_tile_configs(json.load(open(plan))["cfgs"])
     ref = eng.forward(dimg).copy()
     bad = 0

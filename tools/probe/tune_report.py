@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 os.environ["YOLO_TUNE_VERBOSE"] = "1"
 B = int(os.environ.get("B", "32")); size = int(os.environ.get("SIZE", "416"))

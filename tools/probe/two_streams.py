@@ -4,13 +4,13 @@ out of phase).  Same box, interleaved rounds.  env: S (2), PLAN (tile plan json)
 import os, sys, time, json
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from yolo_tensorflow_amd import hip, darknet_io as IO
 
 S = int(os.environ.get("S", "2")); BS = 32 // S
 txt = IO.cfg_text("yolov3"); secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, 0)
 dev = torch.device("cuda", 0)
-plan = json.load(open(os.environ.get("PLAN") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_bf16.json")))["cfgs"]
+plan = json.load(open(os.environ.get("PLAN") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "yolo_tensorflow_amd", "tuned", "yolov3_416_b32_bf16.json")))["cfgs"]
 img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (32, 416, 416, 3), dtype=np.uint8)).to(dev)
 
 

@@ -5,7 +5,7 @@
 set -u
 # SIZE / BATCH (default 416 / 32 = the headline workload) select another workload, e.g. SIZE=608 BATCH=8 bash tools/profile_round.sh r04_608_b8
 # (BASELINE config 4's per-GPU share): the bf16 line, its kernel trace and the PMC passes only.
-R=${1:-r05}
+R=${1:-r06}
 export SIZE=${SIZE:-416} B=${BATCH:-32}
 W="--size $SIZE --batch $B"
 OUT=gpurun_out/prof_$R

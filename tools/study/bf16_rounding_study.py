@@ -4,7 +4,7 @@ does a single-rounding shortcut (fp32 add, one bf16 rounding) do better than the
 clear the threshold by more than the margin."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 

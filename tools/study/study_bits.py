@@ -1,11 +1,11 @@
 """CPU study (oracle only): min IoU of the decoded boxes against the fp32 oracle as a function of the SIGNIFICAND WIDTH of the stored
-activations and folded filters (8 = bf16, 11 = fp16), plain (`dev`) and mean-centred (`cen`, tools/study_centred.py), on the synthetic
+activations and folded filters (8 = bf16, 11 = fp16), plain (`dev`) and mean-centred (`cen`, tools/study/study_centred.py), on the synthetic
 weights with a trained file's batch-norm statistics.  Result (profiles/r04_precision_study.txt): 1 - IoU falls by 4x per 2 bits; 0.999
 needs >= 17 bits -- no 16-bit storage type reaches it on this network, centred or not.
 Usage: study_bits.py [log|real]   (real = the reference's real batch-norm vectors, tests/golden/yolov3_bn_real.npz; profiles/r05_precision_study.txt)"""
 import glob, os, sys
 import numpy as np
-_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, ".."), os.path.join(_H, "..", "tests"), _H]
+_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, "..", ".."), os.path.join(_H, "..", "..", "tests"), _H]
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 import study_centred as S
@@ -17,7 +17,7 @@ def qbits(n):
         return np.ldexp(np.round(m * (1 << n)) / (1 << n), e).astype(np.float32)
     return q
 txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt)
-paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "images", "*.jpg")))
+paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "images", "*.jpg")))
 imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 x_all = np.concatenate([R.input_process(im, 416) for im in imgs])
 noise = np.random.default_rng(5).random((2, 416, 416, 3), dtype=np.float32)

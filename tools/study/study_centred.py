@@ -1,5 +1,5 @@
 """CPU study (oracle only, no device): does MEAN-CENTRED 16-bit storage remove the cancellation that costs bf16 / fp16 storage its box
-accuracy on weights with a trained file's batch-norm statistics (tools/study_precision.py)?
+accuracy on weights with a trained file's batch-norm statistics (tools/study/study_precision.py)?
 
 Scheme `cen`: every stored tensor is x' = round(x - m_c) with a per-channel offset m_c that never touches the 16-bit type:
   conv        z = sum W16 * x'  (zero padding of x', fp32 accumulate)  +  [ b + sum_{taps inside the image} W32 * m_in ]   (exact fold, per
@@ -12,8 +12,8 @@ parameters (no data), shortcut sums of those.
 Prints per scheme: relative rms error of the three raw head tensors, min IoU / max |dscore| over the oracle's candidates, candidates lost."""
 import glob, math, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 from test_gpu_tuned import box_deviation
@@ -103,7 +103,7 @@ def forward_centred(secs, params, x01, q, offs, first=0):
 
 if __name__ == "__main__":
     txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt)
-    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "images", "*.jpg")))
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "images", "*.jpg")))
     from PIL import Image
     imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
     x_all = np.concatenate([R.input_process(im, 416) for im in imgs])

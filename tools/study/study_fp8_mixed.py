@@ -4,8 +4,8 @@ one-type-per-residual-stream rule, darknet_io.store_closure).  Prints per plan: 
 that then runs on the bf16 MFMA (half the e4m3 rate), min / mean IoU and max |dscore| over the fp32 oracle's candidates."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 

@@ -3,7 +3,7 @@ stream to e4m3 after every shortcut add; variant B keeps that stream in bf16 (th
 YOLOv3 at a small size, synthetic weights, both against the fp32 oracle: min IoU / max |dscore| over the oracle's candidates."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 

@@ -5,13 +5,13 @@ Result (profiles/r04_precision_study.txt): the network with trained-file statist
 the heads (the benign one damps it 10-100x), so its sensitivity to storage rounding is a property of that random network, not of offsets."""
 import glob, os, sys
 import numpy as np
-_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, ".."), os.path.join(_H, "..", "tests"), _H]
+_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, "..", ".."), os.path.join(_H, "..", "..", "tests"), _H]
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 import study_centred as S
 from PIL import Image
 txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt)
-paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "images", "*.jpg")))
+paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "images", "*.jpg")))
 imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 x_all = np.concatenate([R.input_process(im, 416) for im in imgs])
 noise = np.random.default_rng(5).random((2, 416, 416, 3), dtype=np.float32)

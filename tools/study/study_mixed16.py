@@ -7,7 +7,7 @@ darknet_io.pair_closure before the emulation).  Prints, per plan, the share of t
 |dscore| per image.  Usage: study_mixed16.py real|log|benign [image indices]   -> profiles/r05_mixed16_study.txt"""
 import glob, os, sys
 import numpy as np
-_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, ".."), os.path.join(_H, "..", "tests"), _H]
+_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, "..", ".."), os.path.join(_H, "..", "..", "tests"), _H]
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 from test_gpu_tuned import box_deviation
@@ -53,7 +53,7 @@ def forward_mixed(secs, params, x01, pair):
 stats = sys.argv[1] if len(sys.argv) > 1 else "real"
 sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 5]
 txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt); isecs = IO.parse_cfg(txt)
-paths = sorted(glob.glob(os.path.join(_H, "..", "tests", "golden", "images", "*.jpg")))
+paths = sorted(glob.glob(os.path.join(_H, "..", "..", "tests", "golden", "images", "*.jpg")))
 imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 x_all = np.concatenate([R.input_process(im, 416) for im in imgs])
 noise = np.random.default_rng(5).random((2, 416, 416, 3), dtype=np.float32)

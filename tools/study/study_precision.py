@@ -13,8 +13,8 @@ Prints per scheme: relative rms error of the three raw head tensors, min IoU / m
 more than 1e-2), candidates lost below the threshold."""
 import glob, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 from test_gpu_tuned import box_deviation
@@ -64,7 +64,7 @@ def forward_scheme(secs, params, x01, q, trunk32=False, in0=False):
 
 
 txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt)
-paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "images", "*.jpg")))
+paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "images", "*.jpg")))
 from PIL import Image
 imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
 x_all = np.concatenate([R.input_process(im, 416) for im in imgs])

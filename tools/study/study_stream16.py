@@ -16,7 +16,7 @@ Prints per plan: MFMA products per algorithmic product (FLOP-weighted) and min I
 Usage: study_stream16.py real|log|benign [image indices, default all six]      -> profiles/r06_stream16_study.txt"""
 import glob, os, sys
 import numpy as np
-_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, ".."), os.path.join(_H, "..", "tests"), _H]
+_H = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [os.path.join(_H, "..", ".."), os.path.join(_H, "..", "..", "tests"), _H]
 from oracle import yolo_ref as R
 from yolo_tensorflow_amd import darknet_io as IO
 from test_gpu_tuned import box_deviation
@@ -64,7 +64,7 @@ def forward_plan(secs, params, x01, abits, wbits):
 def main():
     stats = sys.argv[1] if len(sys.argv) > 1 else "real"
     txt = IO.cfg_text("yolov3"); secs = R.parse_cfg(txt); isecs = IO.parse_cfg(txt)
-    paths = sorted(glob.glob(os.path.join(_H, "..", "tests", "golden", "images", "*.jpg")))
+    paths = sorted(glob.glob(os.path.join(_H, "..", "..", "tests", "golden", "images", "*.jpg")))
     sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(len(paths)))
     imgs = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
     x_all = np.concatenate([R.input_process(im, 416) for im in imgs])

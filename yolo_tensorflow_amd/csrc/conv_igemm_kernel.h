@@ -141,7 +141,7 @@ constexpr bool halo_div_ok(int bw) { for (unsigned r = 0; r < 256; ++r) if (((r 
 // their LDS-DMA, then all wait, then all multiply, and the matrix pipe idles through the first two) shrinks to one barrier per
 // CHUNK (nine K-steps), which the shared halo tile needs.  The two waves of a SIMD (w and w + 4) are started half a K-step apart
 // after every barrier, so that one's DMA-issue / wait / fragment-read startup runs under the other's MFMAs.
-// (Tried on the free-running form and dropped, same-box A/B with tools/kslope.py, YOLOv3-416 batch-32 layer shapes: three and four
+// (Tried on the free-running form and dropped, same-box A/B with tools/probe/kslope.py, YOLOv3-416 batch-32 layer shapes: three and four
 // filter stages -- K-step 0.57 vs 0.59 us on the 13x13 layers, nothing on the others, kept as cfg 43; fragment read-ahead of 2 / 6 /
 // 8 groups instead of 4 -- +-1 %; a direct-store epilogue (v_permlane32_swap pairs, 16-B stores straight from the accumulators, no
 // LDS staging and no barrier) -- bit-identical and not one microsecond faster: what a layer pays outside its K loop is instruction
