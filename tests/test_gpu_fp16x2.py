@@ -18,7 +18,7 @@ from test_gpu_tuned import box_deviation
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.abspath(__file__))
 SPLIT_CFGS = (0, 2, 3, 4, 6, 7, 8, 14, 15, 16, 23, 33, 34, 45, 49, 52)       # (round 6: the pair K loop needs 128-byte rows -- one 32-channel group hi | lo)
-SPLIT_HALO = (40, 41, 43)
+SPLIT_HALO = (40, 41, 43, 57, 58)          # (57, 58: round 6, one wave per SIMD)
 
 
 def _emu_conv(x, w, b, stride, act, res=None):

@@ -12,7 +12,8 @@ bool conv_halo_cfg_ok(const ConvArgs &a, int cfg)
 {
     int bh, bw; halo_cfg_block(cfg, bh, bw);
     if (bh != HALO_B && (a.in_dt == DT_FP8 || a.split)) return false;      // the rectangular blocks are instantiated for bf16 / fp16 storage
-    if (a.pairk && !(a.split && (cfg == 40 || cfg == 41 || cfg == 43))) return false;      // pair K loop: the free-running forms writing pairs
+    if (a.pairk && !(a.split && (cfg == 40 || cfg == 41 || cfg == 43 || cfg == 57 || cfg == 58))) return false;      // pair K loop: the free-running forms writing pairs
+    if ((cfg == 57 || cfg == 58) && !a.pairk) return false;                    // (one wave per SIMD: instantiated for the pair K loop only)
     return halo_ok(a, bh, bw);
 }
 static bool halo_ok(const ConvArgs &a, int bh, int bw)
@@ -89,6 +90,8 @@ hipError_t launch_conv_halo13(const ConvArgs &a, int cfg, hipStream_t s)
             case 40: return launch_h<8, 2, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
             case 41: return launch_h<8, 1, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
             case 43: return launch_h<8, 1, 0, 2, true, 3, true, true, HALO_B, HALO_B, false, true>(a, s);
+            case 57: return launch_h<4, 4, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
+            case 58: return launch_h<4, 2, 0, 2, true, 2, true, true, HALO_B, HALO_B, false, true>(a, s);
             default: return hipErrorInvalidValue;
             }
         switch (cfg) {          // plain fp16 in, pairs out (mixed plans)

@@ -230,7 +230,11 @@ bool conv_cfg_split_ok(int cfg)
 struct CfgDesc { int id, wp, wc, tp, tc, ns, bk, nl, halo; };
 #define X(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 0},
 #define XH(id, wp, wc, tp, tc, ns, bk, nl) {id, wp, wc, tp, tc, ns, bk, nl, 1},
-static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X) CONV_CFGS_HALO_R(XH)};
+// round 6: free-running 13 x 13-block halo forms with ONE wave per SIMD, for the pair K loop (conv_halo13.hip, split-fp16 only): four waves of
+// 176 x 64 (57) / 176 x 32 (58) read every pixel fragment four times per K-step instead of eight -- 42 % fewer LDS bytes per MFMA in a loop whose
+// LDS reads (1 952 cycles per K-step) sit just under its MFMAs (2 112)
+#define CONV_CFGS_HALO_P(X) X(57, 1, 4, 11, 4, 2, 64, 0) X(58, 1, 4, 11, 2, 2, 64, 0)
+static const CfgDesc kCfgs[] = {CONV_CFGS(X) CONV_CFGS_HALO(XH) CONV_CFGS_B(X) CONV_CFGS_HALO_R(XH) CONV_CFGS_HALO_P(XH)};
 #undef X
 #undef XH
 int conv_num_cfgs() { return (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); }
@@ -248,6 +252,7 @@ const char *conv_cfg_name(int cfg)
     static char names[64][32];
     if (cfg < 0 || cfg >= conv_num_cfgs()) return cfg == CONV_CFG_DIRECT ? "direct_c8" : "?";
     const CfgDesc &c = kCfgs[cfg];
+    if (c.id >= 57) { snprintf(names[cfg], sizeof names[cfg], "f176c%d_w4_pair", c.wc * c.tc * 16); return names[cfg]; }
     if (c.id >= 54) { snprintf(names[cfg], sizeof names[cfg], "f%sc%d_s%d", c.tp == 12 ? "10x19" : "5x19", c.wc * c.tc * 16, c.ns); return names[cfg]; }
     snprintf(names[cfg], sizeof names[cfg], "%s%dc%d_s%d_k%d%s%d", c.halo ? (c.id >= 40 ? "f" : "h") : "p", c.wp * c.tp * 16, c.wc * c.tc * 16, c.ns, c.bk, c.nl ? "_L" : "_w", c.nl ? c.nl : c.wp * c.wc);
     return names[cfg];
@@ -324,7 +329,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int cfg, hipStream_t s)
         CONV_CFGS(X) CONV_CFGS_B(X)
 #undef X
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return launch_conv_halo13(a, id, s);
-        CONV_CFGS_HALO(X) CONV_CFGS_HALO_R(X)
+        CONV_CFGS_HALO(X) CONV_CFGS_HALO_R(X) CONV_CFGS_HALO_P(X)
 #undef X
     default: return hipErrorInvalidValue;
     }

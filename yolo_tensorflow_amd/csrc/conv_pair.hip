@@ -22,7 +22,7 @@
 bool conv_cfg_pairk_ok(int cfg, bool split_out)
 {
     if (split_out) {
-        if (cfg == 40 || cfg == 41 || cfg == 43) return true;      // the free-running halo forms (conv_halo13.hip)
+        if (cfg == 40 || cfg == 41 || cfg == 43 || cfg == 57 || cfg == 58) return true;      // the free-running halo forms (conv_halo13.hip)
         switch (cfg) {
 #define X(id, wp, wc, tp, tc, ns, bk, nl) case id: return true;
             CONV_CFGS_PAIRK(X)
