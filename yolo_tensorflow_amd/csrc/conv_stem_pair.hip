@@ -35,6 +35,7 @@ constexpr int SP_LDS = ((SP_IBYTES + 15) / 16 * 16) + SP_MBYTES + 8 * SP_SLAB + 
 
 }  // namespace
 
+template <bool U8>
 __global__ __launch_bounds__(512) void conv_stem_pair_c32_c64(const StemPairArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -66,22 +67,57 @@ __global__ __launch_bounds__(512) void conv_stem_pair_c32_c64(const StemPairArgs
         n = tile / (ty_n * tx_n); const int r = tile - n * ty_n * tx_n; const int ty = r / tx_n;
         oy0 = ty * SP_TH; ox0 = (r - ty * tx_n) * SP_TW;
     };
-    // phase A, first half: this thread's pieces of tile `tile`'s image window into registers (zeros outside the image)
+    // phase A, first half: this thread's share of tile `tile`'s image window into registers (zeros outside the image).  Two forms: 16-byte
+    // pieces of the staged pair image (hi | lo | hi of the 8 padded channels), or -- U8 -- the caller's uint8 [N,H,W,3] batch itself, two pixels
+    // per thread, converted when they are written to LDS with the arithmetic of the two launches this retires (k_preprocess: x * scale
+    // [* mul + add] in fp32; k_split_from_f32: hi = f16(v), lo = f16(v - hi)): 145 us per batch-32 step at 416 x 416
     uint4 pre[SP_PPT];
+    constexpr int UPT = (SP_IH * SP_IW + 511) / 512;       // U8: pixels per thread (2)
+    unsigned pre8[UPT];                                    // U8: r | g << 8 | b << 16 | valid << 24
     auto fetch = [&](int tile) {
         int n, oy0, ox0; tile_origin(tile, n, oy0, ox0);
+        if constexpr (U8) {
 #pragma unroll
-        for (int k = 0; k < SP_PPT; ++k) {
-            const int pc = tid + k * 512;
-            const int px = pc / 3, part = pc - px * 3, r = px / SP_IW, c = px - r * SP_IW;
-            const int y = 2 * oy0 - 2 + r, x = 2 * ox0 - 2 + c;
-            const bool ok = pc < SP_NPIECE && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            pre[k] = ok ? *(const uint4 *)(in + ((size_t)(n * a.H + y) * a.W + x) * 24 + part * 8) : uint4{0u, 0u, 0u, 0u};
+            for (int k = 0; k < UPT; ++k) {
+                const int px = tid + k * 512, r = px / SP_IW, c = px - r * SP_IW;
+                const int y = 2 * oy0 - 2 + r, x = 2 * ox0 - 2 + c;
+                const bool ok = px < SP_IH * SP_IW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                unsigned v = 0;
+                if (ok) { const uint8_t *p = a.in_u8 + ((size_t)(n * a.H + y) * a.W + x) * 3; v = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | (1u << 24); }
+                pre8[k] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SP_PPT; ++k) {
+                const int pc = tid + k * 512;
+                const int px = pc / 3, part = pc - px * 3, r = px / SP_IW, c = px - r * SP_IW;
+                const int y = 2 * oy0 - 2 + r, x = 2 * ox0 - 2 + c;
+                const bool ok = pc < SP_NPIECE && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                pre[k] = ok ? *(const uint4 *)(in + ((size_t)(n * a.H + y) * a.W + x) * 24 + part * 8) : uint4{0u, 0u, 0u, 0u};
+            }
         }
     };
     auto stash = [&]() {
+        if constexpr (U8) {
+            const bool affine = a.in_mul != 1.0f || a.in_add != 0.0f;
 #pragma unroll
-        for (int k = 0; k < SP_PPT; ++k) { const int pc = tid + k * 512; if (pc < SP_NPIECE) *(uint4 *)(I0 + pc * 16) = pre[k]; }
+            for (int k = 0; k < UPT; ++k) {
+                const int px = tid + k * 512;
+                if (px >= SP_IH * SP_IW) continue;
+                uint4 H = uint4{0u, 0u, 0u, 0u}, L = H;
+                if (pre8[k] >> 24) {
+                    float v[3];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { v[e] = (float)((pre8[k] >> (8 * e)) & 0xffu) * a.in_scale; if (affine) v[e] = v[e] * a.in_mul + a.in_add; }
+                    H.x = pack16x2<true>(v[0], v[1]); H.y = pack16x2<true>(v[2], 0.f);
+                    L.x = pack16x2<true>(v[0] - unpack16_lo<true>(H.x), v[1] - unpack16_hi<true>(H.x)); L.y = pack16x2<true>(v[2] - unpack16_lo<true>(H.y), 0.f);
+                }
+                *(uint4 *)(I0 + px * SP_IPIX) = H; *(uint4 *)(I0 + px * SP_IPIX + 16) = L; *(uint4 *)(I0 + px * SP_IPIX + 32) = H;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SP_PPT; ++k) { const int pc = tid + k * 512; if (pc < SP_NPIECE) *(uint4 *)(I0 + pc * 16) = pre[k]; }
+        }
     };
 
     // conv0's filters (32 x 216, pairs): too many registers beside conv1's 144 -- kept in LDS in fragment order, re-read per 16-pixel group
@@ -213,19 +249,20 @@ __global__ __launch_bounds__(512) void conv_stem_pair_c32_c64(const StemPairArgs
 
 bool conv_stem_pair_ok(const StemPairArgs &a)
 {
-    return a.in && a.w0 && a.w1 && a.out && (a.C0 == 16 || a.C0 == 32) && a.Kpad0 >= 216 && a.Kpad1 == 576 && a.out_stride >= 128 && a.H % 2 == 0 && a.W % 2 == 0 &&
+    return (a.in || a.in_u8) && a.w0 && a.w1 && a.out && (a.C0 == 16 || a.C0 == 32) && a.Kpad0 >= 216 && a.Kpad1 == 576 && a.out_stride >= 128 && a.H % 2 == 0 && a.W % 2 == 0 &&
            a.Ho == a.H / 2 && a.Wo == a.W / 2 && !getenv("YOLO_NO_PAIR_STEM");
 }
 
 hipError_t launch_conv_stem_pair(const StemPairArgs &a, hipStream_t s)
 {
     if (!conv_stem_pair_ok(a)) return hipErrorInvalidValue;
-    hipError_t e = conv_opt_in_lds((const void *)conv_stem_pair_c32_c64, SP_LDS);
+    hipError_t e = conv_opt_in_lds(a.in_u8 ? (const void *)conv_stem_pair_c32_c64<true> : (const void *)conv_stem_pair_c32_c64<false>, SP_LDS);
     if (e != hipSuccess) return e;
     static int cus = 0;             // (one device model per process: MI355X)
     if (!cus) { int dev = 0; hipDeviceProp_t p; cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }
     const long tiles = (long)a.N * ((a.Ho + SP_TH - 1) / SP_TH) * ((a.Wo + SP_TW - 1) / SP_TW);
     const long grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL(conv_stem_pair_c32_c64, dim3((unsigned)grid), dim3(512), SP_LDS, s, a);
+    if (a.in_u8) hipLaunchKernelGGL(conv_stem_pair_c32_c64<true>, dim3((unsigned)grid), dim3(512), SP_LDS, s, a);
+    else hipLaunchKernelGGL(conv_stem_pair_c32_c64<false>, dim3((unsigned)grid), dim3(512), SP_LDS, s, a);
     return hipGetLastError();
 }

@@ -146,6 +146,7 @@ hipError_t launch_conv_pair(const ConvArgs &a, int cfg, hipStream_t s);
 // fused conv0 + conv1 of a split-fp16 network (conv_stem_pair.hip): image in three blocks -> conv1's interleaved pairs, conv0 never materialised
 struct StemPairArgs {
     const void *in;                 // [N, H, W, 24] f16: hi | lo | hi blocks of the 8 padded channels
+    const uint8_t *in_u8; float in_scale, in_mul, in_add;      // or (in_u8 != nullptr) the uint8 [N,H,W,3] image itself, converted in the kernel as k_preprocess + k_split_from_f32 would: x * in_scale [* in_mul + in_add], split
     const void *w0; const float *b0; int Kpad0, C0, act0;      // conv0: rows [tap][hi 8 | hi 8 | lo 8] (k = tap * 24 + ...), C0 = 16 or 32 filters
     const void *w1; const float *b1; int Kpad1, act1;          // conv1: rows [tap][W_hi 32 | W_lo 32] (k = tap * 64 + ...), 64 filters
     void *out; int out_stride;      // [N, Ho, Wo, >= 128] f16 interleaved pairs (two 32-channel groups)

@@ -99,6 +99,7 @@ int run_layer(yolo_ctx *c, int i, int n)
             const Layer &A = c->layers[0];
             StemPairArgs t; memset(&t, 0, sizeof t);
             t.in = c->input.ptr; t.w0 = A.d_w; t.b0 = A.d_b; t.Kpad0 = A.kpad; t.C0 = A.filters; t.act0 = A.act;
+            t.in_u8 = c->stem_u8; t.in_scale = c->stem_scale; t.in_mul = c->in_mul; t.in_add = c->in_add;
             t.w1 = L.d_w; t.b1 = L.d_b; t.Kpad1 = L.kpad; t.act1 = L.act;
             t.out = L.out.ptr; t.out_stride = L.out.stride; t.N = n; t.H = A.H; t.W = A.W; t.Ho = L.H; t.Wo = L.W;
             if (c->input.stride != 24 || !conv_stem_pair_ok(t)) return fail(c, YOLO_ERR_STATE, "layer %d: the fused split-fp16 stem does not apply to this plan", i);
@@ -260,7 +261,7 @@ int stage_in(yolo_ctx *c, const void *images, int n, int fmt, int loc, float sca
     }
     // uint8 images of a network whose first layers run as the fused stem: the stem converts the pixels itself (conv_stem.hip, U8 form)
     c->stem_u8 = nullptr;
-    if (fmt == YOLO_IMG_U8 && c->layers.size() > 1 && c->layers[1].stem && !getenv("YOLO_NO_STEM_U8") && (double)npix * 3 < 2147483648.0 && ((size_t)src & 3) == 0) {
+    if (fmt == YOLO_IMG_U8 && c->layers.size() > 1 && (c->layers[1].stem || c->layers[1].pstem) && !getenv("YOLO_NO_STEM_U8") && (double)npix * 3 < 2147483648.0 && ((size_t)src & 3) == 0) {
         c->stem_u8 = (const uint8_t *)src; c->stem_scale = scale; c->stem_u8_n = n;
         return YOLO_OK;
     }
