@@ -26,13 +26,19 @@ done
 else
 python3 bench.py $W --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+# (--tolerance none: the kernel statistics and the timeline of the HEADLINE configuration only; the tolerance line has its own trace, stats_fp16x2)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 --tolerance none > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     D="$OUT/pmc_$(echo $C | cut -d' ' -f1)"
     ITERS=2 timeout 600 rocprofv3 --pmc $C --output-format csv -d "$D" -o p -- python3 tools/prof_forward.py > "$D.log" 2>&1
 done
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $W --no-cpu-baseline --no-latency --parity-images 0 --tolerance none --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace.err"
 python3 tools/step_timeline.py "$OUT/trace" > "$OUT/step_timeline.txt" 2>&1
+if [ "$SIZE" = 416 ] && [ "$B" = 32 ]; then      # the tolerance line's own step, launch by launch
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_fp16x2" -o t -- python3 bench.py --dtype fp16x2 --no-cpu-baseline --no-latency --parity-images 0 --steps 10 --warmup 3 > /dev/null 2> "$OUT/trace_fp16x2.err"
+python3 tools/step_timeline.py "$OUT/trace_fp16x2" > "$OUT/fp16x2_step_timeline.txt" 2>&1
+fi
 python3 tools/summarize_profile.py "$OUT" "$R" "$OUT/summary"
 cp "$OUT/step_timeline.txt" "$OUT/summary/${R}_step_timeline.txt"
+[ -f "$OUT/fp16x2_step_timeline.txt" ] && cp "$OUT/fp16x2_step_timeline.txt" "$OUT/summary/${R}_fp16x2_step_timeline.txt"
 find "$OUT" -name "*.csv" -size +8M -delete       # gpurun_out/ is merged back only up to 64 MiB

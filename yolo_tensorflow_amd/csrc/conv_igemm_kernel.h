@@ -52,6 +52,29 @@ template <bool H16> __device__ __forceinline__ f32x4 mma16(const bf16x8 a, const
     if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// Split-fp16 pairs in the epilogues, on the mixed-precision FMA (round 6): `v_fma_mix_f32` reads an f16 half as one of its operands, so
+// hi + lo of a pair is ONE instruction per value (two conversions and an add before), and `v_fma_mixlo/hi_f16` forms f16(v - hi) into a half
+// of the destination in one (conversion, subtraction, conversion before).  Same values bit for bit: fp32(hi) * 1 + fp32(lo) and v - fp32(hi)
+// are exact in fp32 for a pair made by the split, the one rounding is the final one to f16 (RNE, as v_cvt_pk_f16_f32).
+__device__ __forceinline__ void pair_join2(uint32_t H, uint32_t L, float &a, float &b)
+{
+#ifdef PAIR_NO_MIX          // (probe builds: the conversions and separate add / subtract of rounds 4-5, for the same-box A/B)
+    a = unpack16_lo<true>(H) + unpack16_lo<true>(L); b = unpack16_hi<true>(H) + unpack16_hi<true>(L); return;
+#endif
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(H), "v"(L));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(H), "v"(L));
+}
+__device__ __forceinline__ void pair_split2(float a, float b, uint32_t &H, uint32_t &L)
+{
+    H = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));       // RNE, saturating (FP16_OVFL)
+#ifdef PAIR_NO_MIX
+    L = pack16x2<true>(a - unpack16_lo<true>(H), b - unpack16_hi<true>(H)); return;
+#endif
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(H), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(H), "v"(b));
+    L = l;
+}
 // max(a, b) for finite operands without the sNaN-quieting v_max the compiler puts in front of fmaxf (one instruction, not two)
 __device__ __forceinline__ float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // two floats -> two OCP e4m3 codes (RNE, saturating at +-448) merged into the low / high half of `old`
@@ -816,10 +839,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
         const float slope = a.act == ACT_LEAKY ? 0.1f : 1.0f;
         auto split8 = [](const float *v, u32x4_t &H, u32x4_t &L) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t h = pack16x2<true>(v[2 * q], v[2 * q + 1]);
-                H[q] = h; L[q] = pack16x2<true>(v[2 * q] - unpack16_lo<true>(h), v[2 * q + 1] - unpack16_hi<true>(h));
-            }
+            for (int q = 0; q < 4; ++q) { uint32_t h, l; pair_split2(v[2 * q], v[2 * q + 1], h, l); H[q] = h; L[q] = l; }
         };
         static_for<2>([&](auto halfc) {
             constexpr int HALF = decltype(halfc)::value;
@@ -870,8 +890,8 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
                 if (res) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float f0 = unpack16_lo<true>(H[q]) + unpack16_lo<true>(L[q]), f1 = unpack16_hi<true>(H[q]) + unpack16_hi<true>(L[q]);
-                        const float x0 = unpack16_lo<true>(rh[it][q]) + unpack16_lo<true>(rl[it][q]), x1 = unpack16_hi<true>(rh[it][q]) + unpack16_hi<true>(rl[it][q]);
+                        float f0, f1, x0, x1;
+                        pair_join2(H[q], L[q], f0, f1); pair_join2(rh[it][q], rl[it][q], x0, x1);
                         v[2 * q] = f0 + x0; v[2 * q + 1] = f1 + x1;
                     }
                     split8(v, H, L);
