@@ -221,6 +221,41 @@ def test_fp16x2_fused_stem_equals_the_two_launches(hiplib, size, batch, monkeypa
     assert fused_bytes < plain_bytes
 
 
+@pytest.mark.parametrize("size,batch", [(416, 32), (608, 8)])
+def test_fp16x2_full_size_properties(hiplib, size, batch):
+    """The tolerance line's configuration at BASELINE's full sizes (416 x 416 batch 32; config 4's per-GPU share 608 x 608 x 8), through the
+    size-independent properties the bf16 configuration is held to (tests/test_gpu_network.py): determinism, batch independence (an image
+    alone == the same image in the batch, bit for bit -- the fused stem, the pair K loop and every tile shape walk K in the same order whatever
+    the batch), decode ranges, the captured graph == the eager step, and the NMS tail equal to the oracle's on the device's own tensor."""
+    import torch
+    txt = IO.with_input_size(IO.cfg_text("yolov3"), size)
+    secs = IO.parse_cfg(txt); flat = IO.synth_weights(secs, seed=0)
+    img = np.random.default_rng(3).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    eng = hiplib.Engine(txt, max_batch=batch, dtype=hiplib.FP16X2)
+    eng.set_weights(flat)
+    det = eng.forward(img)
+    rows = sum(3 * (size // s_) ** 2 for s_ in (32, 16, 8))
+    assert det.shape == (batch, rows, 85) and np.isfinite(det).all()
+    assert np.array_equal(det, eng.forward(img))
+    for i in (0, batch // 2 + 1, batch - 1):
+        assert np.array_equal(eng.forward(img[i:i + 1])[0], det[i]), i
+    assert (det[..., 4:] >= 0).all() and (det[..., 4:] <= 1).all() and (det[..., 0:2] >= 0).all() and (det[..., 0:2] <= 1).all() and (det[..., 2:4] > 0).all()
+    eng.forward(img, want_detections=False)
+    res = eng.postprocess(batch, score_thr=0.5, iou_thr=0.5, max_out=20)
+    for b in range(batch):
+        _, os_, oc = R.detect_v3_tf(det[b], 0.5, 0.5, 20)
+        assert np.array_equal(res[b]["score"], os_) and np.array_equal(res[b]["cls"], oc)
+    d_img = torch.from_numpy(img).cuda()
+    boxes = torch.zeros((batch, 20 * 6), dtype=torch.int32, device="cuda"); counts = torch.zeros((batch,), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        eng.detect_graph(d_img, boxes, counts, score_thr=0.5, iou_thr=0.5, max_out=20)
+        eng.synchronize()
+    got = boxes.cpu().numpy().view(hiplib.BOX_DTYPE).reshape(batch, 20); gc = counts.cpu().numpy()
+    for b in range(batch):
+        assert gc[b] == len(res[b]) and np.array_equal(got[b, :gc[b]], res[b])
+    eng.close()
+
+
 def test_fp16x2_refuses_what_it_does_not_serve(hiplib):
     with pytest.raises(hiplib.YoloError, match="split-fp16"):
         hiplib.Engine(IO.cfg_text("yolov1"), dtype=hiplib.FP16X2)

@@ -89,6 +89,13 @@ __device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t shift)
     return shift == 255 ? n : (int)(__umulhi((uint32_t)n, mul) >> shift);
 }
 
+// probe knobs of the pair K loop (tools/probe/ab): fragment read-ahead in first uses, stagger of a SIMD's two waves in 1/64 MFMA-steps
+#ifndef PAIR_PD
+#define PAIR_PD 4
+#endif
+#ifndef PAIR_SLEEP
+#define PAIR_SLEEP 48
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // counted wait with a wave-uniform run-time count (the immediate has to be a constant: a scalar branch ladder)
 template <int MAXN> __device__ __forceinline__ void wait_vmcnt_rt(int n)
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // hi_{TP-1}, lo_{TP-2}, lo_{TP-1}; each is read PD first-uses ahead and pinned there, as in the plain loop.
             if (is_consumer) {
                 constexpr int NF = 2 * TP;
-                constexpr int PD = NF < 4 ? NF : 4;
+                constexpr int PD = NF < PAIR_PD ? NF : PAIR_PD;
                 bf16x8 fwh[TC], fwl[TC], fx[NF];
                 auto rdf = [&](auto pc) {
                     constexpr int p = decltype(pc)::value;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(64 * (WP * WC + NL)) void conv_igemm(const ConvArgs
             // everybody's have, and nobody reads the previous chunk's halo tile any more (the next chunk's pieces overwrite it)
             if constexpr (NS == 2) wait_vmcnt<0>(); else wait_vmcnt_rt<(NS - 2) * (LB + 1)>(NS == 3 ? f_ops1 : f_ops1 + f_ops2);
             block_barrier();
-            if (NC == 8 && wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * (PAIRK ? 48 : 32) / 64);      // half a K-step behind the SIMD's other wave (eight-wave forms: two waves per SIMD)
+            if (NC == 8 && wave_id >= NC / 2) __builtin_amdgcn_s_sleep(TP * TC * (PAIRK ? PAIR_SLEEP : 32) / 64);      // half a K-step behind the SIMD's other wave (eight-wave forms: two waves per SIMD)
             s1 = stamp();
             issue();
             s2 = stamp();
