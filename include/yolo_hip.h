@@ -232,6 +232,10 @@ int yolo_time_forward(yolo_ctx *ctx, int n, int iters, float *total_ms, float *c
  * s_memrealtime).  bench.py prints both next to its roofline fraction: the same binary reads 9 % apart by box, and `frac / (tflops / peak)`
  * is what compares across boxes.  No counterpart in the reference.  stream: a hipStream_t or NULL. */
 int yolo_calibrate(int device, void *stream, int f16, double seconds, float *tflops, float *clock_ghz);
+/* The memory side of the yardstick: GB/s (bytes read + bytes written) of a streaming device-to-device copy between two 1 GiB buffers,
+ * launched back to back for `seconds`.  The boxes of one pool differ in their matrix-pipe clock AND in what their memory system sustains;
+ * bench.py prints both numbers (roofline.calib_tflops, roofline.calib_copy_gbs). */
+int yolo_calibrate_copy(int device, void *stream, double seconds, float *gbs);
 /* Per-layer kernel time (ms, averaged over iters) for batch n into ms_out[num_layers]. */
 int yolo_time_layers(yolo_ctx *ctx, int n, int iters, float *ms_out);
 /* Tries every conv tile configuration on every conv layer at batch n and keeps the fastest. */

@@ -52,6 +52,52 @@ __global__ __launch_bounds__(256) void k_mfma_calib(const cal_u32x4 *__restrict_
 
 }  // namespace
 
+// The memory side of the same yardstick: a streaming copy (16 bytes per lane in, 16 out, grid-stride over the chip) between two buffers
+// far larger than the 256 MiB Infinity Cache, launched back to back for the requested time -> GB/s (read + written bytes).  A conv stack is
+// part matrix-pipe-bound and part traffic-bound, and the boxes of one pool differ in both (round 6: the box with the LOWER MFMA-loop clock
+// read the HIGHER img/s): the pair (calib_tflops, calib_copy_gbs) is what identifies a box class.
+namespace {
+__global__ __launch_bounds__(256) void k_copy_calib(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+}  // namespace
+
+extern "C" int yolo_calibrate_copy(int device, void *stream_, double seconds, float *gbs)
+{
+    if (seconds <= 0 || seconds > 10 || !gbs) return YOLO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return YOLO_ERR_HIP; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t bytes = (size_t)1 << 30, n = bytes / 16;            // 1 GiB in, 1 GiB out
+    uint4 *a = nullptr, *b = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    int rc = YOLO_ERR_HIP;
+    do {
+        if (hipMalloc((void **)&a, bytes) != hipSuccess || hipMalloc((void **)&b, bytes) != hipSuccess) { rc = YOLO_ERR_NOMEM; break; }
+        if (hipMemsetAsync(a, 1, bytes, stream) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) break;
+        auto launch = [&]() { hipLaunchKernelGGL(k_copy_calib, dim3(256 * 8), dim3(256), 0, stream, a, b, n); };
+        (void)hipEventRecord(e0, stream); launch(); (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float one = 0; (void)hipEventElapsedTime(&one, e0, e1);
+        const int reps = std::max(2, (int)(seconds * 1e3 / std::max(one, 0.05f)));
+        (void)hipEventRecord(e1, stream);
+        for (int i = 0; i < reps; ++i) launch();
+        (void)hipEventRecord(e2, stream);
+        if (hipEventSynchronize(e2) != hipSuccess) break;
+        float ms = 0; (void)hipEventElapsedTime(&ms, e1, e2);
+        *gbs = (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+        rc = YOLO_OK;
+    } while (0);
+    if (rc != YOLO_OK) (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
+
 extern "C" int yolo_calibrate(int device, void *stream_, int f16, double seconds, float *tflops, float *clock_ghz)
 {
     if (seconds <= 0 || seconds > 10) return YOLO_ERR_INVALID;

@@ -33,7 +33,7 @@ EXPORTS = [
     "yolo_autotune", "yolo_get_tile_configs", "yolo_set_tile_configs", "yolo_op_conv2d", "yolo_op_conv_num_cfgs", "yolo_op_upsample2x", "yolo_op_reorg",
     "yolo_darknet_boxes", "yolo_last_layer_size", "yolo_last_layer_output", "yolo_op_letterbox",
     "yolo_op_maxpool", "yolo_op_resize_u8", "yolo_op_detections_boxes", "yolo_op_nms_detections", "yolo_forward_letterbox_chw", "yolo_op_decode", "yolo_op_postprocess",
-    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw", "yolo_calibrate", "yolo_op_resize_cv2",
+    "yolo_postprocess_rows", "yolo_op_postprocess_rows", "yolo_last_layer_output_batch", "yolo_head_raw", "yolo_calibrate", "yolo_calibrate_copy", "yolo_op_resize_cv2",
 ]
 # include/yolo_dist.h: the image-sharded detect step
 DIST_EXPORTS = ["yolo_shard_bounds", "yolo_dist_flat_words", "yolo_dist_split_records", "yolo_dist_unique_id", "yolo_dist_create",
@@ -110,6 +110,7 @@ def load_library():
     l.yolo_last_layer_output_batch.argtypes = [P, I, P, C.c_size_t]
     l.yolo_head_raw.argtypes = [P, I, I, P, C.c_size_t]
     l.yolo_calibrate.argtypes = [I, P, I, C.c_double, FP, FP]
+    l.yolo_calibrate_copy.argtypes = [I, P, C.c_double, FP]
     l.yolo_op_resize_cv2.argtypes = [P, I, I, I, I, I, F, P, I]
     l.yolo_shard_bounds.argtypes = [I, I, I, C.POINTER(I), C.POINTER(I)]
     l.yolo_dist_flat_words.argtypes = [I, I]; l.yolo_dist_flat_words.restype = C.c_size_t
@@ -418,6 +419,13 @@ def calibrate(seconds=0.4, f16=False, device=0, stream=None):
     t, g = C.c_float(0), C.c_float(0)
     _op_check(load_library().yolo_calibrate(device, _stream_handle(stream), 1 if f16 else 0, float(seconds), C.byref(t), C.byref(g)), "yolo_calibrate")
     return float(t.value), float(g.value)
+
+
+def calibrate_copy(seconds=0.2, device=0, stream=None):
+    """yolo_calibrate_copy: GB/s (read + written) of a streaming 1 GiB -> 1 GiB device copy -- the memory side of the box's yardstick."""
+    g = C.c_float(0)
+    _op_check(load_library().yolo_calibrate_copy(device, _stream_handle(stream), float(seconds), C.byref(g)), "yolo_calibrate_copy")
+    return float(g.value)
 
 
 def op_upsample2x(x, semantics=SEM_TF, device=0):
