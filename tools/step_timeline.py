@@ -7,7 +7,7 @@ rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Na
 first = os.environ.get("STEP_FIRST", "k_preprocess")
 idx = [i for i, r in enumerate(rows) if first in r[2]]
 if len(idx) < 2:            # the fused stem reads the uint8 image itself: a step starts with the stem launch
-    idx = [i for i, r in enumerate(rows) if "conv_stem_c32_c64" in r[2] or "conv_stem_pair_c32_c64" in r[2]]       # (bf16 / fp16 stem; the split-fp16 stem)
+    idx = [i for i, r in enumerate(rows) if "conv_stem_c32_c64" in r[2] or "conv_stem_pair_" in r[2]]       # (bf16 / fp16 stem; the split-fp16 stem)
 # the last COMPLETE detect step (it ends with the NMS launch; bench.py's closing yolo_time_forward passes have none)
 a, b = idx[-2], idx[-1]
 for k in range(len(idx) - 1, 0, -1):
