@@ -348,3 +348,20 @@ def test_advice_r03_stale_uint8_pointer_and_dirty_list_counter(hiplib):
         for b in range(4):
             assert got_c[b] == len(want[b]) and np.array_equal(got[b, :got_c[b]], want[b])
         eng.close()
+
+
+def test_calibration_yardsticks(hiplib):
+    """yolo_calibrate / yolo_calibrate_copy (what bench.py prints as roofline.calib_tflops / clock_ghz / calib_copy_gbs): a register-resident MFMA
+    loop and a streaming copy.  Plausibility on an MI355X: below the quoted peaks (2.5 PFLOP/s at 2.4 GHz; 8 TB/s), above half of them, and
+    repeatable to a few per cent."""
+    t1, g1 = hiplib.calibrate(0.3)
+    t2, g2 = hiplib.calibrate(0.3)
+    assert 1200 < t1 < 2560 and 1.2 < g1 < 2.45, (t1, g1)
+    assert abs(t1 - t2) / t1 < 0.05 and abs(g1 - g2) / g1 < 0.05
+    th, gh = hiplib.calibrate(0.3, f16=True)
+    assert 1200 < th < 2560 and 1.2 < gh < 2.45
+    c = hiplib.calibrate_copy(0.2)
+    assert 2000 < c < 8200, c
+    with pytest.raises(hiplib.YoloError):
+        hiplib.calibrate(0.0)
+
